@@ -1,0 +1,95 @@
+"""Byte layouts of the scene records that cross the renderer boundary.
+
+numpy mirrors of ``include/pt_types.h`` (which restates the reference's
+``GPUSphere`` / ``GPUEllipsoid`` / ``GPUMaterial`` / ``GPULight`` /
+``GPUVolumetricData`` / ``PushConstants``: reference include/VulkanRenderer.h:16-71,
+include/Ellipsoid.h:11-19).  A structured array of one of these dtypes can be
+handed to the C-ABI or to the oracle without conversion.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+GPU_SPHERE = np.dtype(
+    [("center", "<f4", 3), ("radius", "<f4"), ("color", "<f4", 3), ("materialIndex", "<i4")]
+)
+GPU_ELLIPSOID = np.dtype(
+    [
+        ("center", "<f4", 3),
+        ("padding1", "<f4"),
+        ("radii", "<f4", 3),
+        ("materialIndex", "<i4"),
+        ("color", "<f4", 3),
+        ("padding2", "<f4"),
+        ("rotation", "<f4", 4),  # (x, y, z, w)
+    ]
+)
+GPU_MATERIAL = np.dtype(
+    [
+        ("colorAndAmbient", "<f4", 4),
+        ("diffuseSpecularShiny", "<f4", 4),
+        ("transparencyEmissive", "<f4", 4),
+        ("emissive", "<f4", 4),
+        ("scatterAndAbsorption", "<f4", 4),
+    ]
+)
+GPU_LIGHT = np.dtype(
+    [("position", "<f4", 3), ("intensity", "<f4"), ("color", "<f4", 3), ("padding", "<f4")]
+)
+GPU_VOLUME = np.dtype(
+    [
+        ("position", "<f4", 3),
+        ("scale", "<f4"),
+        ("v0", "<f4", 3),
+        ("resolution_x", "<i4"),
+        ("v1", "<f4", 3),
+        ("resolution_y", "<i4"),
+        ("resolution_z", "<i4"),
+        ("materialIndex", "<i4"),
+        ("padding", "<i4", 2),
+    ]
+)
+PUSH_CONSTANTS = np.dtype(
+    [
+        ("cameraMatrix", "<f4", 16),
+        ("cameraPos", "<f4", 3),
+        ("time", "<f4"),
+        ("numSpheres", "<i4"),
+        ("numEllipsoids", "<i4"),
+        ("numLights", "<i4"),
+        ("numVolumes", "<i4"),
+        ("maxDepth", "<i4"),
+        ("padding1", "<i4"),
+        ("padding2", "<i4"),
+        ("padding3", "<i4"),
+        ("bgColorTop", "<f4", 3),
+        ("padding4", "<f4"),
+        ("bgColorBottom", "<f4", 3),
+        ("padding5", "<f4"),
+    ]
+)
+
+assert GPU_SPHERE.itemsize == 32
+assert GPU_ELLIPSOID.itemsize == 64
+assert GPU_MATERIAL.itemsize == 80
+assert GPU_LIGHT.itemsize == 32
+assert GPU_VOLUME.itemsize == 64
+assert PUSH_CONSTANTS.itemsize == 144
+
+# Work-counter slots (include/pt_types.h, PT_CNT_*).
+COUNTER_NAMES = (
+    "rays",
+    "path_rays",
+    "light_rays",
+    "emissive_rays",
+    "sphere_tests",
+    "ellipsoid_tests",
+    "voxel_samples",
+    "shaded_hits",
+)
+
+# Compiled-in surface shaders, keyed by the path string the reference's
+# ShaderCompiler would have seen (reference src/ShaderCompiler.cpp:131-185:
+# sorted paths get 1, 2, ...; 0 is the built-in Phong).
+SHADER_RAINBOW = "shaders/surface_shaders/rainbow.glsl"
+SHADER_TOON = "shaders/surface_shaders/toon.glsl"
