@@ -1,0 +1,151 @@
+/*
+ * pt_hip.h — C-ABI of the MI355X ray-loop renderer (libpt_hip.so).
+ *
+ * This is the boundary the reference draws with `class VulkanRenderer`
+ * (reference include/VulkanRenderer.h:73-97); the reference has no FFI of its
+ * own, so each entry point names the C++ member it stands in for.  Records are
+ * passed as the byte layouts of pt_types.h.  Every function returns PT_OK (0)
+ * or an error code, never throws, and leaves a message for pt_last_error().
+ *
+ * One PtRenderer = one GPU + one HIP stream.  A renderer is not thread-safe;
+ * use one per device (one process per GPU for multi-GPU work).
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include "pt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtRenderer PtRenderer;
+
+enum {
+  PT_OK = 0,
+  PT_ERR_INVALID = 1, /* bad argument (null, negative count, index out of range) */
+  PT_ERR_HIP = 2,     /* a HIP runtime call failed                              */
+  PT_ERR_NOMEM = 3,   /* device or host allocation failed                       */
+  PT_ERR_STATE = 4    /* call order (e.g. render before update_scene)           */
+};
+
+/* Options for pt_set_option. */
+enum {
+  PT_OPT_FLOAT_OUTPUT = 1, /* 1 (default): also keep the clamped float RGBA frame  */
+  PT_OPT_OBJECT_SOURCE = 2 /* 0 auto, 1 objects staged in LDS, 2 objects read from
+                              global memory (scenes too large for LDS use 2)       */
+};
+
+/* VulkanRenderer::initialize (reference include/VulkanRenderer.h:78,
+ * src/VulkanRenderer.cpp:27-72).  No window: the frame stays in device memory
+ * until pt_readback_*.  `device` is the HIP device ordinal. */
+int pt_create(int width, int height, int device, PtRenderer **out);
+
+/* VulkanRenderer::shutdown / destructor (reference include/VulkanRenderer.h:76,79).
+ * NULL is allowed. */
+void pt_destroy(PtRenderer *r);
+
+/* VulkanRenderer::updateScene (reference include/VulkanRenderer.h:81-87,
+ * src/VulkanRenderer.cpp:794-987).  Copies everything it needs before it
+ * returns; device buffers grow on demand (the reference's are fixed at 100
+ * spheres / ellipsoids / materials, 32 lights / volumes, 50 MB of voxels).
+ * Voxels (x fastest, then y, then z) are uploaded on the first call that
+ * passes any and ignored afterwards, as in the reference
+ * (src/VulkanRenderer.cpp:961-987); pt_reset_voxels() re-arms the upload.
+ * Material indices of spheres, ellipsoids and volumes must lie in
+ * [0, num_materials) — the reference reads out of bounds instead. */
+int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres,
+                    const PtGPUEllipsoid *ellipsoids, int num_ellipsoids,
+                    const PtGPUMaterial *materials, int num_materials,
+                    const PtGPULight *lights, int num_lights,
+                    const PtGPUVolumetricData *volumes, int num_volumes,
+                    const uint8_t *voxels, size_t voxel_bytes);
+
+/* Forget the uploaded voxels so the next pt_update_scene uploads again.
+ * No counterpart in the reference (it can never replace its volume). */
+int pt_reset_voxels(PtRenderer *r);
+
+/* VulkanRenderer::render (reference include/VulkanRenderer.h:89,
+ * src/VulkanRenderer.cpp:1080-1145): enqueue one frame on the renderer's
+ * stream and return.  The object/light/volume counts are taken from `pc` like
+ * the shader does and must not exceed what pt_update_scene received.
+ * `pc->maxDepth` is the bounce limit; the reference shader ignores it and
+ * always uses 10 (shaders/raytrace.comp:603), so maxDepth <= 0 selects 10 and
+ * a caller that wants the reference's images passes 10. */
+int pt_render(PtRenderer *r, const PtPushConstants *pc);
+
+/* VulkanRenderer::present (reference include/VulkanRenderer.h:90): there is no
+ * swapchain; this waits until the frames enqueued so far are complete. */
+int pt_present(PtRenderer *r);
+
+/* The reference reserves a "readback buffer for PPM export" it never creates
+ * (reference include/VulkanRenderer.h:177-179); these are that readback.
+ * They wait for the stream, then copy the frame (or, with row bands set, this
+ * renderer's compact band-major rows) to host memory.
+ *   rgba8: width*rows*4 bytes, R,G,B,255 (the shader's rgba8 image, row 0 = top)
+ *   f32  : width*rows*4 floats, the clamped colour the shader hands to imageStore */
+int pt_readback_rgba8(PtRenderer *r, uint8_t *dst, size_t dst_bytes);
+int pt_readback_f32(PtRenderer *r, float *dst, size_t dst_bytes);
+
+/* VulkanRenderer::getShaderPathToIndexMap (reference include/VulkanRenderer.h:95-97;
+ * filled by ShaderCompiler, reference src/ShaderCompiler.cpp:131-185).  The
+ * surface shaders are compiled-in device functions; the table maps the path
+ * strings the reference would have scanned to the same indices:
+ *   "shaders/surface_shaders/rainbow.glsl" -> 1, ".../toon.glsl" -> 2.
+ * pt_shader_index returns 0 (built-in Phong) for an unknown path, which is
+ * what Material::toGPU does (reference src/SceneWrappers.cpp:13-23). */
+int pt_shader_count(void);
+const char *pt_shader_path(int i); /* i in [0, pt_shader_count()) ; index = i+1 */
+int pt_shader_index(const char *path);
+
+/* Message of the calling thread's most recent failure ("" if none). */
+const char *pt_last_error(void);
+
+/* ---- Entry points without a counterpart in the reference ---- */
+
+/* Multi-GPU image split: this renderer draws only bands band_index,
+ * band_index + band_count, ... of `band_rows` rows each, into a compact
+ * band-major frame (its bands stacked in order).  band_count = 1 restores the
+ * whole frame.  pt_local_rows() tells how many rows the compact frame has. */
+int pt_set_row_bands(PtRenderer *r, int band_rows, int band_index, int band_count);
+int pt_local_rows(PtRenderer *r);
+
+/* Rank-0 side of the gather: `src` holds the compact rgba8 (elem_bytes = 4) or
+ * float (elem_bytes = 16) frames of ranks 0..band_count-1 back to back, each
+ * padded to `stride_rows` rows; writes the assembled height x width frame to
+ * `dst`.  All pointers are device pointers; runs on the renderer's stream. */
+int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
+                      int band_rows, int band_count, int stride_rows);
+
+/* Run the instrumented kernel for one frame (same image, untimed) and return
+ * the PT_CNT_* work counters. */
+int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters);
+
+/* Device pointers of the current output frames (f32 may be NULL). */
+void *pt_device_rgba8(PtRenderer *r);
+void *pt_device_f32(PtRenderer *r);
+/* Render into caller-owned device memory instead (NULL restores the internal
+ * buffers); sizes are width*pt_local_rows()*4 bytes / *16 bytes. */
+int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev);
+
+/* Use a caller-owned hipStream_t (passed as void*); NULL restores the
+ * renderer's own stream. */
+int pt_set_stream(PtRenderer *r, void *hip_stream);
+
+/* hipEvent timing on the renderer's stream: begin/end bracket any number of
+ * pt_render calls; elapsed waits for the end event. */
+int pt_timer_begin(PtRenderer *r);
+int pt_timer_end(PtRenderer *r);
+int pt_timer_elapsed_ms(PtRenderer *r, float *ms);
+
+int pt_set_option(PtRenderer *r, int option, int value);
+
+/* Name of the device the renderer runs on, number of compute units, and the
+ * launch geometry of the last frame (for logs). */
+int pt_device_info(PtRenderer *r, char *name, size_t name_bytes, int *compute_units);
+int pt_last_launch(PtRenderer *r, int *blocks, int *threads, int *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

@@ -1,0 +1,563 @@
+// pt_capi.hip — host side of libpt_hip.so: the C-ABI of include/pt_hip.h over
+// the gfx950 kernels of pt_device.hpp.
+//
+// Stands where the reference has VulkanRenderer + ShaderCompiler
+// (reference src/VulkanRenderer.cpp, src/ShaderCompiler.cpp): device buffers,
+// scene upload (AoS records -> SoA device arrays), per-frame launch, readback.
+#include "../../include/pt_hip.h"
+#include "pt_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define PT_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+// Compiled-in surface shaders in the order the reference's sorted directory
+// scan assigns indices 1, 2, ... (reference src/ShaderCompiler.cpp:93-118,131-185).
+const char *const kShaderPaths[] = {
+    "shaders/surface_shaders/rainbow.glsl",
+    "shaders/surface_shaders/toon.glsl",
+};
+constexpr int kShaderCount = 2;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// Host float helpers with the same operation order as the device code.
+struct H3 { float x, y, z; };
+inline float hdot(H3 a, H3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
+inline H3 hcross(H3 a, H3 b) {
+  return {std::fmaf(a.y, b.z, -(a.z * b.y)), std::fmaf(a.z, b.x, -(a.x * b.z)), std::fmaf(a.x, b.y, -(a.y * b.x))};
+}
+inline H3 hnormalize(H3 a) {
+  float inv = 1.0f / std::sqrt(hdot(a, a));
+  return {a.x * inv, a.y * inv, a.z * inv};
+}
+
+} // namespace
+
+struct PtRenderer {
+  int device = 0;
+  int width = 0, height = 0;
+  int computeUnits = 0;
+  char deviceName[256] = {0};
+  hipStream_t ownStream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t evBegin = nullptr, evEnd = nullptr;
+
+  // scene
+  bool sceneValid = false;
+  int numSpheres = 0, numEllipsoids = 0, numMaterials = 0, numLights = 0, numVolumes = 0;
+  int numEmSpheres = 0, numEmEllipsoids = 0;
+  DevBuf dSpheres, dSphereMat, dEllipsoids, dEllipsoidMat, dMaterials, dLights, dEmSpheres, dEmEllipsoids, dVoxels;
+  bool voxelsUploaded = false;
+  size_t voxelBytes = 0;
+  PtGPUVolumetricData volume0{};
+
+  // output
+  DevBuf dRgba8, dF32, dScratch; // dScratch: tile counter (4 B) + counters (8 x 8 B)
+  void *extRgba8 = nullptr, *extF32 = nullptr;
+  bool floatOutput = true;
+  int objectSource = 0;
+
+  // row bands
+  int bandRows = 0, bandIndex = 0, bandCount = 1;
+  int localRows = 0;
+
+  // last launch
+  int lastBlocks = 0, lastThreads = 0, lastLds = 0;
+};
+
+namespace {
+
+int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {
+  if (bandCount <= 1) return height;
+  int rows = 0;
+  int nBands = (height + bandRows - 1) / bandRows;
+  for (int b = bandIndex; b < nBands; b += bandCount) {
+    int y0 = b * bandRows;
+    rows += std::min(bandRows, height - y0);
+  }
+  return rows;
+}
+
+int ensure_outputs(PtRenderer *r) {
+  size_t px = (size_t)r->width * (size_t)std::max(r->localRows, 1);
+  if (!r->extRgba8) PT_HIP_CHECK(r->dRgba8.reserve(px * 4));
+  if (r->floatOutput && !r->extF32 && !r->extRgba8) PT_HIP_CHECK(r->dF32.reserve(px * 16));
+  PT_HIP_CHECK(r->dScratch.reserve(256));
+  return PT_OK;
+}
+
+int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
+  if (!r || !pc) return fail(PT_ERR_INVALID, "pt_render: null argument");
+  if (!r->sceneValid) return fail(PT_ERR_STATE, "pt_render: pt_update_scene has not been called");
+  if (pc->numSpheres < 0 || pc->numSpheres > r->numSpheres || pc->numEllipsoids < 0 ||
+      pc->numEllipsoids > r->numEllipsoids || pc->numLights < 0 || pc->numLights > r->numLights ||
+      pc->numVolumes < 0 || pc->numVolumes > r->numVolumes)
+    return fail(PT_ERR_INVALID, "pt_render: push-constant object counts exceed the uploaded scene");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  int rc = ensure_outputs(r);
+  if (rc != PT_OK) return rc;
+
+  ptdev::FrameParams P;
+  std::memset(&P, 0, sizeof P);
+  // createCameraRay's pixel-invariant part (reference shaders/raytrace.comp:123-131)
+  H3 eye{pc->cameraPos[0], pc->cameraPos[1], pc->cameraPos[2]};
+  H3 target{2.0f, 1.5f, 0.0f};
+  H3 forward = hnormalize({target.x - eye.x, target.y - eye.y, target.z - eye.z});
+  H3 right = hnormalize(hcross(forward, {0.0f, 1.0f, 0.0f}));
+  H3 up = hnormalize(hcross(right, forward));
+  P.cam[0] = eye.x; P.cam[1] = eye.y; P.cam[2] = eye.z;
+  P.fwd[0] = forward.x; P.fwd[1] = forward.y; P.fwd[2] = forward.z;
+  P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
+  P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
+  P.fov = std::tan((60.0f * 0.017453292519943295f) / 2.0f);
+  P.aspect = (float)r->width / (float)r->height;
+  P.time = pc->time;
+  for (int i = 0; i < 3; ++i) { P.bgTop[i] = pc->bgColorTop[i]; P.bgBottom[i] = pc->bgColorBottom[i]; }
+  P.width = r->width;
+  P.height = r->height;
+  P.localRows = r->localRows;
+  P.bandRows = r->bandCount > 1 ? r->bandRows : std::max(r->height, 1);
+  P.bandIndex = r->bandCount > 1 ? r->bandIndex : 0;
+  P.bandCount = std::max(r->bandCount, 1);
+  P.numSpheres = pc->numSpheres;
+  P.numEllipsoids = pc->numEllipsoids;
+  P.numLights = pc->numLights;
+  P.numVolumes = pc->numVolumes;
+  P.numEmSpheres = r->numEmSpheres;
+  P.numEmEllipsoids = r->numEmEllipsoids;
+  P.maxBounces = pc->maxDepth > 0 ? pc->maxDepth : 10;
+  P.tilesX = (r->width + ptdev::kTileDim - 1) / ptdev::kTileDim;
+  int tilesY = (r->localRows + ptdev::kTileDim - 1) / ptdev::kTileDim;
+  P.numTiles = P.tilesX * tilesY;
+  if (pc->numVolumes > 0) {
+    const PtGPUVolumetricData &v = r->volume0;
+    for (int i = 0; i < 3; ++i) {
+      P.volPos[i] = v.position[i];
+      P.v0[i] = v.v0[i];
+      P.v1[i] = v.v1[i];
+      P.boxMin[i] = v.position[i] + v.v0[i]; // reference shaders/raytrace.comp:549-550
+      P.boxMax[i] = v.position[i] + v.v1[i];
+      P.extent[i] = v.v1[i] - v.v0[i];       // reference shaders/raytrace.comp:503
+    }
+    P.res[0] = v.resolution_x; P.res[1] = v.resolution_y; P.res[2] = v.resolution_z;
+    P.volMaterial = v.materialIndex;
+  }
+  P.spheres = (const float4 *)r->dSpheres.p;
+  P.sphereMat = (const int *)r->dSphereMat.p;
+  P.ellipsoids = (const float4 *)r->dEllipsoids.p;
+  P.ellipsoidMat = (const int *)r->dEllipsoidMat.p;
+  P.materials = (const float4 *)r->dMaterials.p;
+  P.lights = (const float4 *)r->dLights.p;
+  P.emSpheres = (const int *)r->dEmSpheres.p;
+  P.emEllipsoids = (const int *)r->dEmEllipsoids.p;
+  P.voxels = (const uint8_t *)r->dVoxels.p;
+  P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8.p);
+  P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr));
+  P.tileCounter = (unsigned int *)r->dScratch.p;
+  P.counters = (unsigned long long *)((char *)r->dScratch.p + 64);
+
+  if (P.numTiles <= 0) return PT_OK;
+
+  // Launch geometry: persistent workgroups, 16 waves per CU.  Objects are
+  // staged in LDS when they fit (<= 80 KiB: two 512-thread groups per CU;
+  // <= 160 KiB: one 1024-thread group); otherwise read from global memory.
+  size_t ldsBytes = ((size_t)P.numSpheres + 4 * (size_t)P.numEllipsoids) * sizeof(float4);
+  bool useLds = ldsBytes <= 160 * 1024;
+  if (r->objectSource == 1 && !useLds)
+    return fail(PT_ERR_INVALID, "pt_render: scene does not fit the 160 KiB LDS (PT_OPT_OBJECT_SOURCE=1)");
+  if (r->objectSource == 2) useLds = false;
+  int threads, blocksPerCu;
+  if (!useLds) { ldsBytes = 0; threads = 256; blocksPerCu = 4; }
+  else if (ldsBytes <= 40 * 1024) { threads = 256; blocksPerCu = 4; }
+  else if (ldsBytes <= 80 * 1024) { threads = 512; blocksPerCu = 2; }
+  else { threads = 1024; blocksPerCu = 1; }
+  long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
+  long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
+  int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
+
+  PT_HIP_CHECK(hipMemsetAsync(r->dScratch.p, 0, counted ? 256 : 4, r->stream));
+  dim3 grid(blocks), block(threads);
+  if (counted) {
+    if (useLds) {
+      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+      hipLaunchKernelGGL((ptdev::pt_render_kernel<true, true>), grid, block, ldsBytes, r->stream, P);
+    } else {
+      hipLaunchKernelGGL((ptdev::pt_render_kernel<true, false>), grid, block, 0, r->stream, P);
+    }
+  } else {
+    if (useLds) {
+      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+      hipLaunchKernelGGL((ptdev::pt_render_kernel<false, true>), grid, block, ldsBytes, r->stream, P);
+    } else {
+      hipLaunchKernelGGL((ptdev::pt_render_kernel<false, false>), grid, block, 0, r->stream, P);
+    }
+  }
+  PT_HIP_CHECK(hipGetLastError());
+  r->lastBlocks = blocks;
+  r->lastThreads = threads;
+  r->lastLds = (int)ldsBytes;
+  return PT_OK;
+}
+
+template <typename T>
+int upload(DevBuf &buf, const std::vector<T> &host, hipStream_t stream) {
+  if (host.empty()) return PT_OK;
+  PT_HIP_CHECK(buf.reserve(host.size() * sizeof(T)));
+  PT_HIP_CHECK(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+  return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_create(int width, int height, int device, PtRenderer **out) {
+  if (!out) return fail(PT_ERR_INVALID, "pt_create: out is null");
+  *out = nullptr;
+  if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 30))
+    return fail(PT_ERR_INVALID, "pt_create: bad frame size");
+  int nDev = 0;
+  PT_HIP_CHECK(hipGetDeviceCount(&nDev));
+  if (device < 0 || device >= nDev) return fail(PT_ERR_INVALID, "pt_create: no such HIP device");
+  PT_HIP_CHECK(hipSetDevice(device));
+  PtRenderer *r = new (std::nothrow) PtRenderer();
+  if (!r) return fail(PT_ERR_NOMEM, "pt_create: out of host memory");
+  r->device = device;
+  r->width = width;
+  r->height = height;
+  r->localRows = height;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)); }
+  r->computeUnits = prop.multiProcessorCount;
+  std::snprintf(r->deviceName, sizeof r->deviceName, "%s (%s)", prop.name, prop.gcnArchName);
+  e = hipStreamCreateWithFlags(&r->ownStream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+  r->stream = r->ownStream;
+  (void)hipEventCreate(&r->evBegin);
+  (void)hipEventCreate(&r->evEnd);
+  int rc = ensure_outputs(r);
+  if (rc != PT_OK) { pt_destroy(r); return rc; }
+  *out = r;
+  return PT_OK;
+}
+
+void pt_destroy(PtRenderer *r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  if (r->stream) (void)hipStreamSynchronize(r->stream);
+  DevBuf *bufs[] = {&r->dSpheres, &r->dSphereMat, &r->dEllipsoids, &r->dEllipsoidMat, &r->dMaterials, &r->dLights,
+                    &r->dEmSpheres, &r->dEmEllipsoids, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch};
+  for (DevBuf *b : bufs) b->release();
+  if (r->evBegin) (void)hipEventDestroy(r->evBegin);
+  if (r->evEnd) (void)hipEventDestroy(r->evEnd);
+  if (r->ownStream) (void)hipStreamDestroy(r->ownStream);
+  delete r;
+}
+
+int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, const PtGPUEllipsoid *ellipsoids,
+                    int num_ellipsoids, const PtGPUMaterial *materials, int num_materials, const PtGPULight *lights,
+                    int num_lights, const PtGPUVolumetricData *volumes, int num_volumes, const uint8_t *voxels,
+                    size_t voxel_bytes) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_update_scene: renderer is null");
+  if (num_spheres < 0 || num_ellipsoids < 0 || num_materials < 0 || num_lights < 0 || num_volumes < 0)
+    return fail(PT_ERR_INVALID, "pt_update_scene: negative count");
+  if ((num_spheres && !spheres) || (num_ellipsoids && !ellipsoids) || (num_materials && !materials) ||
+      (num_lights && !lights) || (num_volumes && !volumes))
+    return fail(PT_ERR_INVALID, "pt_update_scene: null array with a non-zero count");
+  for (int i = 0; i < num_spheres; ++i)
+    if (spheres[i].materialIndex < 0 || spheres[i].materialIndex >= num_materials)
+      return fail(PT_ERR_INVALID, "pt_update_scene: sphere " + std::to_string(i) + " has material index " +
+                                      std::to_string(spheres[i].materialIndex) + " outside [0, " +
+                                      std::to_string(num_materials) + ")");
+  for (int i = 0; i < num_ellipsoids; ++i)
+    if (ellipsoids[i].materialIndex < 0 || ellipsoids[i].materialIndex >= num_materials)
+      return fail(PT_ERR_INVALID, "pt_update_scene: ellipsoid " + std::to_string(i) + " has a material index out of range");
+  if (num_volumes > 0) {
+    const PtGPUVolumetricData &v = volumes[0];
+    if (v.materialIndex < 0 || v.materialIndex >= num_materials)
+      return fail(PT_ERR_INVALID, "pt_update_scene: volume 0 has a material index out of range");
+    if (v.resolution_x <= 0 || v.resolution_y <= 0 || v.resolution_z <= 0 ||
+        (long long)v.resolution_x * v.resolution_y * v.resolution_z > 0x7fffffffll)
+      return fail(PT_ERR_INVALID, "pt_update_scene: volume 0 resolution must be positive with fewer than 2^31 voxels");
+  }
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  // The previous frame may still be reading the buffers we are about to refill.
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+
+  // AoS records -> SoA device arrays.
+  // Spheres: the reference repacks to {center, radius, materialIndex}
+  // (reference src/VulkanRenderer.cpp:803-822); colour is dropped.
+  std::vector<float4> hs((size_t)num_spheres);
+  std::vector<int> hsm((size_t)num_spheres);
+  std::vector<int> emS;
+  for (int i = 0; i < num_spheres; ++i) {
+    hs[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
+    hsm[i] = spheres[i].materialIndex;
+    if (materials[hsm[i]].transparencyEmissive[1] > 0.0f) emS.push_back(i);
+  }
+  // Ellipsoids: centre + qw, 1/radii + max radius, -q.xyz, -2 q.xyz.  1/radii is
+  // the same IEEE division hitEllipsoid does per test (reference
+  // shaders/raytrace.comp:178); negation and doubling are exact.
+  std::vector<float4> he((size_t)num_ellipsoids * 4);
+  std::vector<int> hem((size_t)num_ellipsoids);
+  std::vector<int> emE;
+  for (int i = 0; i < num_ellipsoids; ++i) {
+    const PtGPUEllipsoid &e = ellipsoids[i];
+    float maxR = std::max(std::max(e.radii[0], e.radii[1]), e.radii[2]); // raytrace.comp:467
+    he[4 * i + 0] = make_float4(e.center[0], e.center[1], e.center[2], e.rotation[3]);
+    he[4 * i + 1] = make_float4(1.0f / e.radii[0], 1.0f / e.radii[1], 1.0f / e.radii[2], maxR);
+    he[4 * i + 2] = make_float4(-e.rotation[0], -e.rotation[1], -e.rotation[2], 0.0f);
+    he[4 * i + 3] = make_float4(-2.0f * e.rotation[0], -2.0f * e.rotation[1], -2.0f * e.rotation[2], 0.0f);
+    hem[i] = e.materialIndex;
+    if (materials[hem[i]].transparencyEmissive[1] > 0.0f) emE.push_back(i);
+  }
+  // Lights: vec4(position, intensity) (reference src/VulkanRenderer.cpp:876-883).
+  std::vector<float4> hl((size_t)num_lights);
+  for (int i = 0; i < num_lights; ++i)
+    hl[i] = make_float4(lights[i].position[0], lights[i].position[1], lights[i].position[2], lights[i].intensity);
+  std::vector<PtGPUMaterial> hm(materials, materials + num_materials);
+
+  int rc;
+  if ((rc = upload(r->dSpheres, hs, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dSphereMat, hsm, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dEllipsoids, he, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dEllipsoidMat, hem, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dMaterials, hm, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dLights, hl, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dEmSpheres, emS, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dEmEllipsoids, emE, r->stream)) != PT_OK) return rc;
+
+  if (num_volumes > 0) {
+    r->volume0 = volumes[0];
+    size_t need = (size_t)volumes[0].resolution_x * volumes[0].resolution_y * volumes[0].resolution_z;
+    if (voxels && voxel_bytes > 0 && !r->voxelsUploaded) {
+      // Uploaded once (reference src/VulkanRenderer.cpp:961-987).  Voxels the
+      // file did not supply read as 0.
+      PT_HIP_CHECK(r->dVoxels.reserve(need + 16));
+      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream));
+      PT_HIP_CHECK(hipMemcpyAsync(r->dVoxels.p, voxels, std::min(need, voxel_bytes), hipMemcpyHostToDevice, r->stream));
+      r->voxelsUploaded = true;
+      r->voxelBytes = need;
+    } else if (!r->voxelsUploaded || r->voxelBytes < need) {
+      // A volume without data marches through zeros.
+      PT_HIP_CHECK(r->dVoxels.reserve(need + 16));
+      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream));
+      r->voxelBytes = need;
+    }
+  }
+  // The host vectors die at return: finish the copies first.
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+
+  r->numSpheres = num_spheres;
+  r->numEllipsoids = num_ellipsoids;
+  r->numMaterials = num_materials;
+  r->numLights = num_lights;
+  r->numVolumes = num_volumes;
+  r->numEmSpheres = (int)emS.size();
+  r->numEmEllipsoids = (int)emE.size();
+  r->sceneValid = true;
+  return PT_OK;
+}
+
+int pt_reset_voxels(PtRenderer *r) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_reset_voxels: renderer is null");
+  r->voxelsUploaded = false;
+  return PT_OK;
+}
+
+int pt_render(PtRenderer *r, const PtPushConstants *pc) { return launch_frame(r, pc, false); }
+
+int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters) {
+  if (!counters) return fail(PT_ERR_INVALID, "pt_render_counted: counters is null");
+  int rc = launch_frame(r, pc, true);
+  if (rc != PT_OK) return rc;
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  PT_HIP_CHECK(hipMemcpy(counters, (char *)r->dScratch.p + 64, PT_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_present(PtRenderer *r) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_present: renderer is null");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  return PT_OK;
+}
+
+int pt_readback_rgba8(PtRenderer *r, uint8_t *dst, size_t dst_bytes) {
+  if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_rgba8: null argument");
+  size_t bytes = (size_t)r->width * r->localRows * 4;
+  if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_rgba8: destination too small");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  const void *src = r->extRgba8 ? r->extRgba8 : r->dRgba8.p;
+  PT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_readback_f32(PtRenderer *r, float *dst, size_t dst_bytes) {
+  if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_f32: null argument");
+  const void *src = r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr);
+  if (!src) return fail(PT_ERR_STATE, "pt_readback_f32: float output is disabled");
+  size_t bytes = (size_t)r->width * r->localRows * 16;
+  if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_f32: destination too small");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  PT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_shader_count(void) { return kShaderCount; }
+
+const char *pt_shader_path(int i) { return (i >= 0 && i < kShaderCount) ? kShaderPaths[i] : nullptr; }
+
+int pt_shader_index(const char *path) {
+  if (!path) return 0;
+  for (int i = 0; i < kShaderCount; ++i)
+    if (std::strcmp(path, kShaderPaths[i]) == 0) return i + 1;
+  return 0;
+}
+
+const char *pt_last_error(void) { return g_last_error.c_str(); }
+
+int pt_set_row_bands(PtRenderer *r, int band_rows, int band_index, int band_count) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_set_row_bands: renderer is null");
+  if (band_count < 1 || band_index < 0 || band_index >= band_count || (band_count > 1 && band_rows < 1))
+    return fail(PT_ERR_INVALID, "pt_set_row_bands: need band_rows >= 1 and 0 <= band_index < band_count");
+  r->bandRows = band_rows;
+  r->bandIndex = band_index;
+  r->bandCount = band_count;
+  r->localRows = compute_local_rows(r->height, band_rows, band_index, band_count);
+  return PT_OK;
+}
+
+int pt_local_rows(PtRenderer *r) { return r ? r->localRows : 0; }
+
+int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes, int band_rows, int band_count,
+                      int stride_rows) {
+  if (!r || !src || !dst) return fail(PT_ERR_INVALID, "pt_assemble_bands: null argument");
+  if ((elem_bytes != 4 && elem_bytes != 16) || band_rows < 1 || band_count < 1 || stride_rows < 1)
+    return fail(PT_ERR_INVALID, "pt_assemble_bands: bad geometry");
+  int maxLocal = compute_local_rows(r->height, band_rows, 0, band_count);
+  if (stride_rows < maxLocal) return fail(PT_ERR_INVALID, "pt_assemble_bands: stride_rows smaller than a rank's frame");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  dim3 block(256), grid((r->width + 255) / 256, r->height);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<uint32_t>), grid, block, 0, r->stream, (const uint32_t *)src,
+                       (uint32_t *)dst, r->width, r->height, band_rows, band_count, stride_rows);
+  else
+    hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<float4>), grid, block, 0, r->stream, (const float4 *)src,
+                       (float4 *)dst, r->width, r->height, band_rows, band_count, stride_rows);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+void *pt_device_rgba8(PtRenderer *r) { return r ? (r->extRgba8 ? r->extRgba8 : r->dRgba8.p) : nullptr; }
+void *pt_device_f32(PtRenderer *r) {
+  return r ? (r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr)) : nullptr;
+}
+
+int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_set_output: renderer is null");
+  if (!rgba8_dev && f32_dev) return fail(PT_ERR_INVALID, "pt_set_output: a float frame needs an rgba8 frame too");
+  r->extRgba8 = rgba8_dev;
+  r->extF32 = f32_dev;
+  return PT_OK;
+}
+
+int pt_set_stream(PtRenderer *r, void *hip_stream) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_set_stream: renderer is null");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  r->stream = hip_stream ? (hipStream_t)hip_stream : r->ownStream;
+  return PT_OK;
+}
+
+int pt_timer_begin(PtRenderer *r) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_timer_begin: renderer is null");
+  PT_HIP_CHECK(hipEventRecord(r->evBegin, r->stream));
+  return PT_OK;
+}
+int pt_timer_end(PtRenderer *r) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_timer_end: renderer is null");
+  PT_HIP_CHECK(hipEventRecord(r->evEnd, r->stream));
+  return PT_OK;
+}
+int pt_timer_elapsed_ms(PtRenderer *r, float *ms) {
+  if (!r || !ms) return fail(PT_ERR_INVALID, "pt_timer_elapsed_ms: null argument");
+  PT_HIP_CHECK(hipEventSynchronize(r->evEnd));
+  PT_HIP_CHECK(hipEventElapsedTime(ms, r->evBegin, r->evEnd));
+  return PT_OK;
+}
+
+int pt_set_option(PtRenderer *r, int option, int value) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_set_option: renderer is null");
+  switch (option) {
+  case PT_OPT_FLOAT_OUTPUT: r->floatOutput = value != 0; return PT_OK;
+  case PT_OPT_OBJECT_SOURCE:
+    if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: object source must be 0, 1 or 2");
+    r->objectSource = value;
+    return PT_OK;
+  default: return fail(PT_ERR_INVALID, "pt_set_option: unknown option");
+  }
+}
+
+int pt_device_info(PtRenderer *r, char *name, size_t name_bytes, int *compute_units) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_device_info: renderer is null");
+  if (name && name_bytes) std::snprintf(name, name_bytes, "%s", r->deviceName);
+  if (compute_units) *compute_units = r->computeUnits;
+  return PT_OK;
+}
+
+int pt_last_launch(PtRenderer *r, int *blocks, int *threads, int *lds_bytes) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_last_launch: renderer is null");
+  if (blocks) *blocks = r->lastBlocks;
+  if (threads) *threads = r->lastThreads;
+  if (lds_bytes) *lds_bytes = r->lastLds;
+  return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,709 @@
+// pt_device.hpp — gfx950 device code of the per-pixel ray loop.
+//
+// One lane owns one pixel at a time and runs it as a small state machine:
+// every trip round the main loop each lane holds exactly one ray (a path ray,
+// a light shadow ray or an emissive-object occlusion ray), the whole wave
+// tests its 64 rays against the object list in one wave-uniform loop over
+// LDS-staged objects, and then each lane consumes its result and emits its
+// next ray.  A lane whose pixel is finished takes the next pixel of the
+// wave's tile pool (ballot + prefix count), so the intersection loop always
+// runs with every lane live until the frame runs out of pixels.
+//
+// What it computes follows the reference shader function by function
+// (reference shaders/raytrace.comp, shaders/surface_shaders/*.glsl); the
+// floating-point contract is:
+//   dot(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+//   cross(a,b).x  = fma(a.y,b.z, -(a.z*b.y))
+//   a + s*b       = fma(s, b, a)   for points / directions (madd3)
+//   normalize(v)  = v * (1 / sqrt(dot(v,v)));  vec / scalar = IEEE division
+//   sphere  : c = fma(-r, r, dot(oc,oc)), disc = fma(hb, hb, -c)
+//   ellipsoid: disc = fma(hb, hb, -(a*c));  volume: acc = fma(1-acc, alpha, acc)
+//   everything else: one IEEE operation per source operator, left to right.
+// The translation unit must be compiled with -ffp-contract=off so that these
+// explicit fmaf calls are the only fused operations.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptdev {
+
+constexpr float kMaxDistance = 1e10f; // raytrace.comp:94
+constexpr float kEpsilon = 0.001f;    // raytrace.comp:95
+constexpr int kTileDim = 16;          // pixels per tile edge (4 sub-tiles of 8x8)
+constexpr int kTilePixels = kTileDim * kTileDim;
+
+struct FrameParams {
+  // camera basis, computed once per frame on the host with the same float
+  // operations createCameraRay uses per pixel (raytrace.comp:121-131)
+  float cam[3], fwd[3], right[3], up[3];
+  float aspect, fov;
+  float time;
+  float bgTop[3], bgBottom[3];
+  int width, height;     // full frame
+  int localRows;         // rows this renderer draws (compact band-major frame)
+  int bandRows, bandIndex, bandCount;
+  int numSpheres, numEllipsoids, numLights, numVolumes;
+  int numEmSpheres, numEmEllipsoids;
+  int maxBounces;
+  int tilesX, numTiles;
+  // volume 0 (raytrace.comp:538-550); boxMin/boxMax/extent precomputed
+  float volPos[3], v0[3], v1[3], boxMin[3], boxMax[3], extent[3];
+  int res[3];
+  int volMaterial;
+  // scene, SoA
+  const float4 *spheres;    // (cx, cy, cz, r)
+  const int *sphereMat;
+  const float4 *ellipsoids; // 4 per ellipsoid: (c, qw) (1/radii, maxRadius) (-q.xyz, 0) (-2q.xyz, 0)
+  const int *ellipsoidMat;
+  const float4 *materials;  // 5 per material, as GPUMaterial
+  const float4 *lights;     // (pos, intensity)
+  const int *emSpheres;     // indices of spheres whose material has emissiveStrength > 0, ascending
+  const int *emEllipsoids;
+  const uint8_t *voxels;
+  uint32_t *outRgba8;
+  float4 *outF32;           // may be null
+  unsigned int *tileCounter;
+  unsigned long long *counters; // PT_CNT_COUNT slots, instrumented kernel only
+};
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+__device__ __forceinline__ V3 add3(V3 a, V3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 mul3(V3 a, V3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 scale3(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 div3s(V3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 neg3(V3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) {
+  return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+}
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+  return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+             __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ V3 madd3(V3 a, float s, V3 b) {
+  return mk3(__builtin_fmaf(s, b.x, a.x), __builtin_fmaf(s, b.y, a.y), __builtin_fmaf(s, b.z, a.z));
+}
+__device__ __forceinline__ float length3(V3 a) { return __builtin_sqrtf(dot3(a, a)); }
+__device__ __forceinline__ V3 normalize3(V3 a) {
+  float inv = 1.0f / length3(a);
+  return scale3(a, inv);
+}
+// GLSL max/min/clamp: max(x,y) = (x<y)?y:x ; min(x,y) = (y<x)?y:x (NaN in x propagates)
+__device__ __forceinline__ float glmax(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ float glmin(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float glclamp(float x, float lo, float hi) { return glmin(glmax(x, lo), hi); }
+__device__ __forceinline__ float glfract(float x) { return x - __builtin_floorf(x); }
+
+// rotateByQuaternion with q.xyz and 2*q.xyz supplied (raytrace.comp:99-108):
+// t = 2*cross(q, v) == cross(2q, v) exactly; v' = (v + qw*t) + cross(q, t)
+__device__ __forceinline__ V3 rotate_q(V3 v, V3 q, V3 q2, float qw) {
+  V3 t = cross3(q2, v);
+  return add3(madd3(v, qw, t), cross3(q, t));
+}
+
+struct Ellipsoid {
+  V3 c; float qw;
+  V3 invR; float maxR;
+  V3 nq;   // -q.xyz  (the conjugate's vector part, raytrace.comp:111-115)
+  V3 nq2;  // -2*q.xyz
+};
+
+// ---- surface shaders (compiled-in; index = position in the sorted path list + 1) ----
+
+// rainbow.glsl:1-8
+__device__ __forceinline__ float hue2rgb(float p, float q, float t) {
+  if (t < 0.0f) t += 1.0f;
+  if (t > 1.0f) t -= 1.0f;
+  if (t < 1.0f / 6.0f) return p + ((q - p) * 6.0f) * t;
+  if (t < 0.5f) return q;
+  if (t < 2.0f / 3.0f) return p + ((q - p) * (2.0f / 3.0f - t)) * 6.0f;
+  return p;
+}
+// rainbow.glsl:10-22
+__device__ __forceinline__ V3 hsl2rgb(float h, float s, float l) {
+  float H = glfract(h);
+  float S = glclamp(s, 0.0f, 1.0f);
+  float L = glclamp(l, 0.0f, 1.0f);
+  if (S == 0.0f) return mk3(L, L, L);
+  float q = (L < 0.5f) ? (L * (1.0f + S)) : ((L + S) - L * S);
+  float p = 2.0f * L - q;
+  return mk3(hue2rgb(p, q, H + 1.0f / 3.0f), hue2rgb(p, q, H), hue2rgb(p, q, H - 1.0f / 3.0f));
+}
+// rainbow.glsl:24-50 — returns result.emissive (result.color is 0)
+__device__ __forceinline__ V3 rainbow_emissive(V3 hitPoint, float emissiveStrength, float time) {
+  V3 sweepDir = normalize3(mk3(1.0f, 0.5f, 0.25f));
+  float phase = dot3(hitPoint, sweepDir) * 2.0f + time * 0.002f;
+  float cosVal = cosf(phase);
+  float hue = glfract(0.5f + 0.5f * cosVal);
+  return scale3(hsl2rgb(hue, 1.0f, 0.5f), emissiveStrength);
+}
+
+__device__ __forceinline__ uint32_t unorm8(float c) {
+  if (c != c) return 0u;
+  return (uint32_t)(int)__builtin_rintf(c * 255.0f);
+}
+
+// Lane states: which kind of ray the lane has in flight.
+enum : int {
+  ST_IDLE = 0,       // wants a pixel
+  ST_PATH = 1,       // primary / bounce ray, closest hit        (raytrace.comp:610)
+  ST_LIGHT = 2,      // getShadowFactor for light k, Phong        (raytrace.comp:345)
+  ST_TOON_LIGHT = 3, // getShadowFactor for light k, toon shader  (toon.glsl:19)
+  ST_EM_SPHERE = 4,  // emissive-sphere occlusion ray             (raytrace.comp:431)
+  ST_EM_ELLIPSOID = 5 // emissive-ellipsoid occlusion ray         (raytrace.comp:469)
+};
+
+template <bool COUNT, bool LDS_OBJECTS>
+__global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
+  extern __shared__ float4 s_obj[]; // spheres, then 4 float4 per ellipsoid
+  const int Ns = P.numSpheres, Ne = P.numEllipsoids;
+  if (LDS_OBJECTS) {
+    for (int i = threadIdx.x; i < Ns; i += blockDim.x) s_obj[i] = P.spheres[i];
+    for (int i = threadIdx.x; i < 4 * Ne; i += blockDim.x) s_obj[Ns + i] = P.ellipsoids[i];
+    __syncthreads();
+  }
+  const float4 *__restrict__ g_sph = P.spheres;
+  const float4 *__restrict__ g_ell = P.ellipsoids;
+#define PT_SPH(i) (LDS_OBJECTS ? s_obj[(i)] : g_sph[(i)])
+#define PT_ELL(j, k) (LDS_OBJECTS ? s_obj[Ns + 4 * (j) + (k)] : g_ell[4 * (j) + (k)])
+
+  const int lane = threadIdx.x & 63;
+  const unsigned long long laneMaskLt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  // wave-uniform tile pool
+  int poolNext = 0, poolEnd = 0;
+  bool exhausted = false;
+
+  // per-lane pixel / path state
+  int state = ST_IDLE;
+  int outIdx = 0;
+  int bounce = 0;
+  V3 curO = mk3(0, 0, 0), curD = mk3(0, 0, 1); // current path ray
+  float thr = 1.0f;                            // throughput (always a multiple of (1,1,1))
+  V3 fin = mk3(0, 0, 0);                       // finalColor
+  // ray in flight
+  V3 rO = mk3(0, 0, 0), rD = mk3(0, 0, 1);
+  float rTmin = kEpsilon, rTmax = -1.0f;
+  // hit being shaded
+  V3 hitP = mk3(0, 0, 0), hitN = mk3(0, 0, 1), viewDir = mk3(0, 0, 1);
+  int hitMat = 0;
+  V3 lit = mk3(0, 0, 0);     // calculateLighting's finalColor / toon finalColor
+  V3 pending = mk3(0, 0, 0); // contribution added if the occlusion ray is clear
+  int k = 0;                 // light index or emissive-list cursor
+
+  unsigned int cRays = 0, cPath = 0, cLight = 0, cEmis = 0, cShaded = 0, cVoxel = 0;
+
+  for (;;) {
+    // ------------------------------------------------------------------
+    // 1. refill idle lanes from the wave's tile pool
+    // ------------------------------------------------------------------
+    unsigned long long idleMask = __ballot(state == ST_IDLE);
+    while (idleMask != 0ull && !exhausted) {
+      if (poolNext == poolEnd) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(P.tileCounter, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= (unsigned int)P.numTiles) { exhausted = true; break; }
+        poolNext = (int)t * kTilePixels;
+        poolEnd = poolNext + kTilePixels;
+      }
+      const int avail = poolEnd - poolNext;
+      const int nIdle = __popcll(idleMask);
+      const int take = avail < nIdle ? avail : nIdle;
+      const int rank = __popcll(idleMask & laneMaskLt);
+      if (state == ST_IDLE && rank < take) {
+        const int p = poolNext + rank;
+        const int tile = p / kTilePixels, q = p % kTilePixels;
+        const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+        const int sub = q >> 6, w = q & 63;
+        const int x = tx * kTileDim + (sub & 1) * 8 + (w & 7);
+        const int ly = ty * kTileDim + (sub >> 1) * 8 + (w >> 3);
+        const int band = ly / P.bandRows;
+        const int gy = (band * P.bandCount + P.bandIndex) * P.bandRows + (ly - band * P.bandRows);
+        if (x < P.width && ly < P.localRows && gy < P.height) {
+          // main() + createCameraRay (raytrace.comp:686-700, 121-140)
+          float uvx = (float)x / (float)P.width;
+          float uvy = (float)gy / (float)P.height;
+          uvy = 1.0f - uvy;
+          float sx = ((uvx - 0.5f) * P.aspect) * P.fov;
+          float sy = (uvy - 0.5f) * P.fov;
+          curO = ld3(P.cam);
+          curD = normalize3(madd3(madd3(ld3(P.fwd), sx, ld3(P.right)), sy, ld3(P.up)));
+          outIdx = ly * P.width + x;
+          fin = mk3(0, 0, 0);
+          thr = 1.0f;
+          bounce = 0;
+          rO = curO; rD = curD; rTmin = kEpsilon; rTmax = kMaxDistance;
+          state = ST_PATH;
+          if (COUNT) cPath++;
+        }
+      }
+      poolNext += take;
+      idleMask = __ballot(state == ST_IDLE);
+    }
+    if (__ballot(state != ST_IDLE) == 0ull) break;
+
+    // ------------------------------------------------------------------
+    // 2. traceRay for every live lane (raytrace.comp:212-241): wave-uniform
+    //    loop over the objects; bestIdx < Ns is a sphere, else an ellipsoid
+    // ------------------------------------------------------------------
+    float bestT = rTmax;
+    int bestIdx = -1;
+    if (state != ST_IDLE) {
+      if (COUNT) cRays++;
+      const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
+      const float tMin = rTmin;
+      // hitSphere (raytrace.comp:142-168), point/normal deferred to the winner
+#define PT_SPHERE_DISC(S, HB, DISC)                                              \
+  {                                                                              \
+    const float ocx = ox - S.x, ocy = oy - S.y, ocz = oz - S.z;                  \
+    HB = __builtin_fmaf(ocz, dz, __builtin_fmaf(ocy, dy, ocx * dx));             \
+    const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)); \
+    const float cc = __builtin_fmaf(-S.w, S.w, dd);                              \
+    DISC = __builtin_fmaf(HB, HB, -cc);                                          \
+  }
+#define PT_SPHERE_ACCEPT(IDX, HB, DISC)                                          \
+  if (!(DISC < 0.0f)) {                                                          \
+    const float sq = __builtin_sqrtf(DISC);                                      \
+    float t = -HB - sq;                                                          \
+    bool ok = !(t < tMin || t > bestT);                                          \
+    if (!ok) {                                                                   \
+      t = -HB + sq;                                                              \
+      ok = !(t < tMin || t > bestT);                                             \
+    }                                                                            \
+    if (ok) { bestT = t; bestIdx = (IDX); }                                      \
+  }
+      int i = 0;
+      for (; i + 4 <= Ns; i += 4) {
+        const float4 s0 = PT_SPH(i), s1 = PT_SPH(i + 1), s2 = PT_SPH(i + 2), s3 = PT_SPH(i + 3);
+        float hb0, hb1, hb2, hb3, d0, d1, d2, d3;
+        PT_SPHERE_DISC(s0, hb0, d0)
+        PT_SPHERE_DISC(s1, hb1, d1)
+        PT_SPHERE_DISC(s2, hb2, d2)
+        PT_SPHERE_DISC(s3, hb3, d3)
+        const bool any = !(d0 < 0.0f) | !(d1 < 0.0f) | !(d2 < 0.0f) | !(d3 < 0.0f);
+        if (__ballot(any) != 0ull) {
+          PT_SPHERE_ACCEPT(i, hb0, d0)
+          PT_SPHERE_ACCEPT(i + 1, hb1, d1)
+          PT_SPHERE_ACCEPT(i + 2, hb2, d2)
+          PT_SPHERE_ACCEPT(i + 3, hb3, d3)
+        }
+      }
+      for (; i < Ns; ++i) {
+        const float4 s0 = PT_SPH(i);
+        float hb0, d0;
+        PT_SPHERE_DISC(s0, hb0, d0)
+        if (__ballot(!(d0 < 0.0f)) != 0ull) { PT_SPHERE_ACCEPT(i, hb0, d0) }
+      }
+      // hitEllipsoid (raytrace.comp:171-210)
+      for (int j = 0; j < Ne; ++j) {
+        const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
+        const V3 nq = xyz(e2), nq2 = xyz(e3);
+        const V3 oc = rotate_q(mk3(ox - e0.x, oy - e0.y, oz - e0.z), nq, nq2, e0.w);
+        const V3 dir = rotate_q(mk3(dx, dy, dz), nq, nq2, e0.w);
+        const V3 invR = xyz(e1);
+        const V3 ocS = mul3(oc, invR), dS = mul3(dir, invR);
+        const float a = dot3(dS, dS);
+        const float hb = dot3(ocS, dS);
+        const float c = dot3(ocS, ocS) - 1.0f;
+        const float disc = __builtin_fmaf(hb, hb, -(a * c));
+        if (__ballot(!(disc < 0.0f)) != 0ull) {
+          if (!(disc < 0.0f)) {
+            const float sq = __builtin_sqrtf(disc);
+            float t = (-hb - sq) / a;
+            bool ok = !(t < tMin || t > bestT);
+            if (!ok) {
+              t = (-hb + sq) / a;
+              ok = !(t < tMin || t > bestT);
+            }
+            if (ok) { bestT = t; bestIdx = Ns + j; }
+          }
+        }
+      }
+    }
+
+    // ------------------------------------------------------------------
+    // 3. each live lane consumes its result and runs until it has emitted
+    //    its next ray or finished its pixel
+    // ------------------------------------------------------------------
+    if (state != ST_IDLE) {
+      const bool hitAny = bestIdx >= 0;
+      // Labels of the per-lane coroutine.  `step` says where to resume.
+      enum { GO_PATH_RESULT, GO_NEXT_LIGHT, GO_NEXT_TOON_LIGHT, GO_NEXT_EM_SPHERE, GO_NEXT_EM_ELLIPSOID,
+             GO_AFTER_LIGHTING, GO_FINISH, GO_EMITTED };
+      int step;
+      if (state == ST_PATH) {
+        step = GO_PATH_RESULT;
+      } else if (state == ST_LIGHT) {
+        if (!hitAny) {
+          // raytrace.comp:348-363
+          const float4 L = P.lights[k];
+          const float4 m0 = P.materials[5 * hitMat], m1 = P.materials[5 * hitMat + 1];
+          const V3 surfaceColor = xyz(m0);
+          const V3 lightVec = sub3(xyz(L), hitP);
+          const float distance = length3(lightVec);
+          const V3 lightDir = div3s(lightVec, distance);
+          const float attenuation = L.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
+          const float diffuseStrength = glmax(0.0f, dot3(hitN, lightDir));
+          const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseStrength), attenuation);
+          const V3 halfDir = normalize3(add3(lightDir, viewDir));
+          const float specularStrength = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
+          const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularStrength), attenuation);
+          lit = add3(lit, add3(diffuse, specular));
+        }
+        k++;
+        step = GO_NEXT_LIGHT;
+      } else if (state == ST_TOON_LIGHT) {
+        if (!hitAny) {
+          // toon.glsl:22-39
+          const float4 L = P.lights[k];
+          const float4 m0 = P.materials[5 * hitMat], m1 = P.materials[5 * hitMat + 1];
+          const V3 surfaceColor = xyz(m0);
+          const V3 lightVec = sub3(xyz(L), hitP);
+          const float distance = length3(lightVec);
+          const V3 lightDir = div3s(lightVec, distance);
+          const float attenuation = L.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
+          const float diffuseRaw = glmax(0.0f, dot3(hitN, lightDir));
+          const float diffuseQuantized = diffuseRaw > 0.6f ? 1.0f : (diffuseRaw > 0.3f ? 0.5f : 0.0f);
+          const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseQuantized), attenuation);
+          const V3 halfDir = normalize3(add3(lightDir, viewDir));
+          const float specularRaw = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
+          const float specularQuantized = specularRaw > 0.8f ? 1.0f : 0.0f;
+          const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularQuantized), attenuation);
+          lit = add3(lit, add3(diffuse, specular));
+        }
+        k++;
+        step = GO_NEXT_TOON_LIGHT;
+      } else if (state == ST_EM_SPHERE) {
+        if (!hitAny) lit = add3(lit, pending); // raytrace.comp:433-440
+        k++;
+        step = GO_NEXT_EM_SPHERE;
+      } else { // ST_EM_ELLIPSOID
+        if (!hitAny) lit = add3(lit, pending); // raytrace.comp:471-477
+        k++;
+        step = GO_NEXT_EM_ELLIPSOID;
+      }
+
+      while (step != GO_EMITTED) {
+        switch (step) {
+        case GO_PATH_RESULT: {
+          // traceIterative body after traceRay (raytrace.comp:612-680)
+          // --- rayMarchVolume(currentRay, hit ? rec.t : MAX_DISTANCE, 0) (:534-585) ---
+          float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
+          float volumeAlpha = 0.0f;
+          if (P.numVolumes > 0) {
+            const float maxDist = hitAny ? bestT : kMaxDistance;
+            // intersectBox (:519-532)
+            const V3 invDir = mk3(1.0f / (curD.x + 1e-8f), 1.0f / (curD.y + 1e-8f), 1.0f / (curD.z + 1e-8f));
+            const V3 t0 = mul3(sub3(ld3(P.boxMin), curO), invDir);
+            const V3 t1 = mul3(sub3(ld3(P.boxMax), curO), invDir);
+            const V3 tmn = mk3(glmin(t0.x, t1.x), glmin(t0.y, t1.y), glmin(t0.z, t1.z));
+            const V3 tmx = mk3(glmax(t0.x, t1.x), glmax(t0.y, t1.y), glmax(t0.z, t1.z));
+            float tNear = glmax(glmax(tmn.x, tmn.y), tmn.z);
+            float tFar = glmin(glmin(tmx.x, tmx.y), tmx.z);
+            if (tFar >= tNear && tFar > 0.0f) {
+              tNear = glmax(tNear, 0.0f);
+              tFar = glmin(tFar, maxDist);
+              const float4 m4 = P.materials[5 * P.volMaterial + 4];
+              const float absorptionCoeff = m4.w;
+              const float rxf = (float)P.res[0], ryf = (float)P.res[1], rzf = (float)P.res[2];
+              const int rx = P.res[0], ry = P.res[1], rz = P.res[2];
+              float t = tNear;
+              float acc = 0.0f;
+              int stepCount = 0;
+              while (t < tFar && stepCount < 500) {
+                // sampleVolume (:485-517), nearest neighbour
+                const V3 pos = madd3(curO, t, curD);
+                const V3 rel = sub3(pos, ld3(P.volPos));
+                float density = 0.0f;
+                if (!(rel.x < P.v0[0] || rel.y < P.v0[1] || rel.z < P.v0[2] ||
+                      rel.x > P.v1[0] || rel.y > P.v1[1] || rel.z > P.v1[2])) {
+                  const float ux = (rel.x - P.v0[0]) / P.extent[0];
+                  const float uy = (rel.y - P.v0[1]) / P.extent[1];
+                  const float uz = (rel.z - P.v0[2]) / P.extent[2];
+                  int ix = (int)(ux * rxf), iy = (int)(uy * ryf), iz = (int)(uz * rzf);
+                  ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix);
+                  iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
+                  iz = iz < 0 ? 0 : (iz > rz - 1 ? rz - 1 : iz);
+                  const int index = ix + iy * rx + iz * rx * ry;
+                  density = (float)P.voxels[index] / 255.0f;
+                }
+                const float sampleAlpha = density * absorptionCoeff;
+                acc = __builtin_fmaf(1.0f - acc, sampleAlpha, acc);
+                t += 0.02f;
+                stepCount++;
+              }
+              if (COUNT) cVoxel += (unsigned int)stepCount;
+              // mix(vec3(-1), materialColor*acc, float(acc >= 1e-4)) = x*(1-a) + y*a
+              const float a = (acc >= 0.0001f) ? 1.0f : 0.0f;
+              const float oma = 1.0f - a;
+              volX = -1.0f * oma + (m4.x * acc) * a;
+              volY = -1.0f * oma + (m4.y * acc) * a;
+              volZ = -1.0f * oma + (m4.z * acc) * a;
+            }
+            if (volX >= 0.0f) { // :618-620
+              volumeAlpha = glclamp(length3(mk3(volX, volY, volZ)) / length3(mk3(1.0f, 1.0f, 1.0f)), 0.0f, 1.0f);
+            }
+          }
+          if (volumeAlpha > 0.0f) { // :624-627
+            fin = add3(fin, scale3(mk3(thr * volX, thr * volY, thr * volZ), volumeAlpha));
+            thr = thr * (1.0f - volumeAlpha);
+          }
+          if (!hitAny) { // :672-679
+            const V3 unitDir = normalize3(curD);
+            const float t = 0.5f * (unitDir.y + 1.0f);
+            const float omt = 1.0f - t;
+            const V3 bg = mk3(P.bgBottom[0] * omt + P.bgTop[0] * t, P.bgBottom[1] * omt + P.bgTop[1] * t,
+                              P.bgBottom[2] * omt + P.bgTop[2] * t);
+            fin = add3(fin, scale3(bg, thr));
+            step = GO_FINISH;
+            break;
+          }
+          // hit record of the winner
+          hitP = madd3(curO, bestT, curD);
+          if (bestIdx < Ns) { // hitSphere :161-165
+            const float4 s = PT_SPH(bestIdx);
+            hitN = scale3(sub3(hitP, xyz(s)), 1.0f / s.w);
+            hitMat = P.sphereMat[bestIdx];
+          } else { // hitEllipsoid :198-207
+            const int j = bestIdx - Ns;
+            const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
+            const V3 nq = xyz(e2), nq2 = xyz(e3);
+            const V3 oc = rotate_q(sub3(curO, xyz(e0)), nq, nq2, e0.w);
+            const V3 dir = rotate_q(curD, nq, nq2, e0.w);
+            const V3 invR = xyz(e1);
+            const V3 localPoint = madd3(oc, bestT, dir);
+            const V3 normalLocal = mul3(mul3(localPoint, invR), invR);
+            hitN = normalize3(rotate_q(normalLocal, neg3(nq), neg3(nq2), e0.w));
+            hitMat = P.ellipsoidMat[j];
+          }
+          const float4 m0 = P.materials[5 * hitMat];
+          const float4 m2 = P.materials[5 * hitMat + 2];
+          const V3 surfaceColor = xyz(m0);
+          const float emissiveStrength = m2.y;
+          if (emissiveStrength > 0.0f) // :637-639
+            fin = add3(fin, scale3(scale3(surfaceColor, thr), emissiveStrength));
+          viewDir = normalize3(sub3(curO, hitP)); // :642
+          // calculateLighting (:286-336)
+          if (COUNT) cShaded++;
+          const int shaderFunctionIndex = (int)m2.z;
+          if (shaderFunctionIndex != 0) {
+            if (shaderFunctionIndex == 1) { // rainbow: color 0 + emissive
+              lit = add3(mk3(0, 0, 0), rainbow_emissive(hitP, emissiveStrength, P.time));
+              step = GO_AFTER_LIGHTING;
+            } else if (shaderFunctionIndex == 2) { // toon.glsl:11
+              lit = scale3(surfaceColor, m0.w);
+              k = 0;
+              step = GO_NEXT_TOON_LIGHT;
+            } else { // no branch of the generated chain matches: color 0 + emissive 0
+              lit = mk3(0, 0, 0);
+              step = GO_AFTER_LIGHTING;
+            }
+          } else {
+            lit = scale3(surfaceColor, m0.w);
+            if (emissiveStrength > 0.0f) lit = add3(lit, scale3(surfaceColor, emissiveStrength));
+            k = 0;
+            step = GO_NEXT_LIGHT;
+          }
+          break;
+        }
+        case GO_NEXT_LIGHT:
+        case GO_NEXT_TOON_LIGHT: {
+          if (k < P.numLights) { // getShadowFactor (:243-253)
+            const float4 L = P.lights[k];
+            const V3 lightVec = sub3(xyz(L), hitP);
+            const float distToLight = length3(lightVec);
+            rO = hitP;
+            rD = div3s(lightVec, distToLight);
+            rTmin = kEpsilon;
+            rTmax = distToLight;
+            state = (step == GO_NEXT_LIGHT) ? ST_LIGHT : ST_TOON_LIGHT;
+            if (COUNT) cLight++;
+            step = GO_EMITTED;
+          } else if (step == GO_NEXT_LIGHT) {
+            k = 0;
+            step = GO_NEXT_EM_SPHERE;
+          } else { // toon.glsl:42-47: result.color + result.emissive
+            const float4 m0 = P.materials[5 * hitMat];
+            const float4 m2 = P.materials[5 * hitMat + 2];
+            V3 em = mk3(0, 0, 0);
+            if (m2.y > 0.0f) em = scale3(xyz(m0), m2.y);
+            lit = add3(lit, em);
+            step = GO_AFTER_LIGHTING;
+          }
+          break;
+        }
+        case GO_NEXT_EM_SPHERE: { // raytrace.comp:367-443, over the precomputed emissive list
+          step = GO_NEXT_EM_ELLIPSOID;
+          while (k < P.numEmSpheres) {
+            const int si = P.emSpheres[k];
+            if (si >= Ns) { k = P.numEmSpheres; break; }
+            const float4 s = PT_SPH(si);
+            const int mi = P.sphereMat[si];
+            const float4 sm0 = P.materials[5 * mi];
+            const float4 sm2 = P.materials[5 * mi + 2];
+            float sphereEmissive = sm2.y;
+            V3 emissiveColor = xyz(sm0);
+            const V3 toSphere = sub3(xyz(s), hitP);
+            const float distToSphere = length3(toSphere);
+            const V3 dirToSphere = div3s(toSphere, distToSphere);
+            const int sphereShaderIndex = (int)sm2.z;
+            bool skip = false;
+            if (sphereShaderIndex != 0) { // :377-414
+              const V3 approximateHitPoint = sub3(xyz(s), scale3(dirToSphere, s.w));
+              if (sphereShaderIndex == 1) {
+                emissiveColor = rainbow_emissive(approximateHitPoint, sphereEmissive, P.time);
+              } else if (sphereShaderIndex == 2) {
+                // toon keeps result.emissive = surfaceColor * emissiveStrength (toon.glsl:45-47);
+                // its light loop only feeds result.color, which this caller drops
+                emissiveColor = scale3(xyz(sm0), sphereEmissive);
+              } else {
+                emissiveColor = mk3(0, 0, 0);
+              }
+              if (length3(emissiveColor) < 0.001f) skip = true;
+            }
+            if (!skip) {
+              const float alignment = dot3(hitN, dirToSphere);
+              if (alignment > 0.0f) {
+                rO = madd3(hitP, kEpsilon, hitN);
+                rD = dirToSphere;
+                rTmin = kEpsilon;
+                rTmax = (distToSphere - s.w) - kEpsilon;
+                const float attenuation =
+                    sphereEmissive / ((1.0f + 0.5f * distToSphere) + (0.1f * distToSphere) * distToSphere);
+                pending = scale3(scale3(emissiveColor, alignment), attenuation);
+                state = ST_EM_SPHERE;
+                if (COUNT) cEmis++;
+                step = GO_EMITTED;
+                break;
+              }
+            }
+            k++;
+          }
+          if (step != GO_EMITTED) k = 0;
+          break;
+        }
+        case GO_NEXT_EM_ELLIPSOID: { // raytrace.comp:445-480
+          step = GO_AFTER_LIGHTING;
+          while (k < P.numEmEllipsoids) {
+            const int ei = P.emEllipsoids[k];
+            if (ei >= Ne) { k = P.numEmEllipsoids; break; }
+            const float4 e0 = PT_ELL(ei, 0), e1 = PT_ELL(ei, 1);
+            const int mi = P.ellipsoidMat[ei];
+            const float4 em0 = P.materials[5 * mi];
+            const float4 em2 = P.materials[5 * mi + 2];
+            const V3 toE = sub3(xyz(e0), hitP);
+            const float distE = length3(toE);
+            const V3 dirE = div3s(toE, distE);
+            const float alignment = dot3(hitN, dirE);
+            if (alignment > 0.0f) {
+              rO = madd3(hitP, kEpsilon, hitN);
+              rD = dirE;
+              rTmin = kEpsilon;
+              rTmax = (distE - e1.w) - kEpsilon;
+              const float attenuation = em2.y / ((1.0f + 0.5f * distE) + (0.1f * distE) * distE);
+              pending = scale3(scale3(xyz(em0), alignment), attenuation);
+              state = ST_EM_ELLIPSOID;
+              if (COUNT) cEmis++;
+              step = GO_EMITTED;
+              break;
+            }
+            k++;
+          }
+          break;
+        }
+        case GO_AFTER_LIGHTING: { // raytrace.comp:645-671
+          const float4 m1 = P.materials[5 * hitMat + 1];
+          const float4 m2 = P.materials[5 * hitMat + 2];
+          const float transparency = m2.x;
+          const float reflectivity = m1.w;
+          bool cont = false;
+          if (reflectivity > 0.01f) {
+            const float surfaceOpacity = (1.0f - reflectivity) * (1.0f - transparency);
+            fin = add3(fin, scale3(scale3(lit, thr), surfaceOpacity));
+            thr = thr * reflectivity;
+            const float kk = 2.0f * dot3(hitN, curD); // reflect(I,N) = I - 2 dot(N,I) N
+            const V3 reflectDir = sub3(curD, scale3(hitN, kk));
+            curO = madd3(hitP, kEpsilon, hitN);
+            curD = reflectDir;
+            cont = true;
+          } else if (transparency > 0.01f) {
+            const float opacity = 1.0f - transparency;
+            fin = add3(fin, scale3(scale3(lit, thr), opacity));
+            thr = thr * transparency;
+            curO = madd3(hitP, kEpsilon, curD);
+            cont = true;
+          } else {
+            fin = add3(fin, scale3(lit, thr));
+          }
+          step = GO_FINISH;
+          if (cont) {
+            bounce++;
+            // loop head of traceIterative (:605-606)
+            if (bounce < P.maxBounces && !(length3(mk3(thr, thr, thr)) < 0.001f)) {
+              rO = curO; rD = curD; rTmin = kEpsilon; rTmax = kMaxDistance;
+              state = ST_PATH;
+              if (COUNT) cPath++;
+              step = GO_EMITTED;
+            }
+          }
+          break;
+        }
+        case GO_FINISH: { // main() :703-704
+          const float r = glclamp(fin.x, 0.0f, 1.0f), g = glclamp(fin.y, 0.0f, 1.0f), b = glclamp(fin.z, 0.0f, 1.0f);
+          P.outRgba8[outIdx] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
+          if (P.outF32) P.outF32[outIdx] = make_float4(r, g, b, 1.0f);
+          state = ST_IDLE;
+          step = GO_EMITTED;
+          break;
+        }
+        default:
+          step = GO_EMITTED;
+          break;
+        }
+      }
+    }
+  }
+
+  if (COUNT) {
+    // wave reduction, then one atomic per counter per wave
+    unsigned long long v[8];
+    v[0] = cRays; v[1] = cPath; v[2] = cLight; v[3] = cEmis;
+    v[4] = (unsigned long long)cRays * (unsigned long long)(Ns > 0 ? Ns : 0);
+    v[5] = (unsigned long long)cRays * (unsigned long long)(Ne > 0 ? Ne : 0);
+    v[6] = cVoxel; v[7] = cShaded;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unsigned long long x = v[c];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0) atomicAdd(&P.counters[c], x);
+    }
+  }
+#undef PT_SPH
+#undef PT_ELL
+#undef PT_SPHERE_DISC
+#undef PT_SPHERE_ACCEPT
+}
+
+// De-interleave the compact band-major frames of `bandCount` renderers into
+// one height x width frame.  Source frame of renderer p starts at
+// p * strideRows rows; elements are uint32 (rgba8) or float4.
+template <typename T>
+__global__ void pt_assemble_bands_kernel(const T *__restrict__ src, T *__restrict__ dst, int width, int height,
+                                         int bandRows, int bandCount, int strideRows) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gy = blockIdx.y;
+  if (x >= width || gy >= height) return;
+  const int band = gy / bandRows;
+  const int owner = band % bandCount;
+  const int localBand = band / bandCount;
+  const int ly = localBand * bandRows + (gy - band * bandRows);
+  dst[(size_t)gy * width + x] = src[((size_t)owner * strideRows + ly) * width + x];
+}
+
+} // namespace ptdev

@@ -1,0 +1,181 @@
+"""HipRenderer — Python mirror of the reference's ``VulkanRenderer`` interface
+(reference include/VulkanRenderer.h:73-97) over the C-ABI of include/pt_hip.h.
+
+Method names and argument meaning follow the reference class:
+``initialize`` / ``updateScene`` / ``render`` / ``present`` /
+``getShaderPathToIndexMap`` / ``shutdown``; ``readback*`` replace the
+swapchain (the frame is returned as a numpy array instead of shown).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from . import types as T
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None or a.size == 0:
+        return None
+    return a.ctypes.data
+
+
+class HipRenderer:
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._lib = None
+        self.width = 0
+        self.height = 0
+        # The reference shader ignores PushConstants.maxDepth and always runs 10
+        # bounces (reference shaders/raytrace.comp:603).  True reproduces that;
+        # False makes render() honour maxDepth.
+        self.reference_bounce_limit = False
+
+    # -- VulkanRenderer::initialize(window, width, height); no window here
+    def initialize(self, width: int, height: int, device: int = 0) -> bool:
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.pt_create(width, height, device, C.byref(h))
+        if rc != 0:
+            # the reference reports failure as `false` + a message on stderr
+            import sys
+
+            print("HipRenderer.initialize failed:", self._lib.pt_last_error().decode(), file=sys.stderr)
+            return False
+        self._h = h
+        self.width, self.height = width, height
+        return True
+
+    # -- VulkanRenderer::shutdown (idempotent)
+    def shutdown(self) -> None:
+        if self._h:
+            self._lib.pt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
+    # -- VulkanRenderer::getShaderPathToIndexMap
+    def getShaderPathToIndexMap(self) -> Dict[str, int]:
+        lib = self._lib or _lib.load()
+        return {lib.pt_shader_path(i).decode(): i + 1 for i in range(lib.pt_shader_count())}
+
+    # -- VulkanRenderer::updateScene(spheres, ellipsoids, materials, lights, volumes, voxelData = {})
+    def updateScene(self, spheres, ellipsoids, materials, lights, volumes, voxelData=None) -> None:
+        arrs = []
+        for a, dt in ((spheres, T.GPU_SPHERE), (ellipsoids, T.GPU_ELLIPSOID), (materials, T.GPU_MATERIAL),
+                      (lights, T.GPU_LIGHT), (volumes, T.GPU_VOLUME)):
+            a = np.zeros(0, dt) if a is None else np.ascontiguousarray(a, dtype=dt)
+            arrs.append(a)
+        vox = None if voxelData is None else np.ascontiguousarray(voxelData, dtype=np.uint8)
+        _lib.check(self._lib.pt_update_scene(
+            self._h, _ptr(arrs[0]), len(arrs[0]), _ptr(arrs[1]), len(arrs[1]), _ptr(arrs[2]), len(arrs[2]),
+            _ptr(arrs[3]), len(arrs[3]), _ptr(arrs[4]), len(arrs[4]), _ptr(vox), 0 if vox is None else vox.size))
+
+    def _pc(self, pushConstants) -> np.ndarray:
+        pc = np.array(pushConstants, dtype=T.PUSH_CONSTANTS, copy=True).reshape(())
+        if self.reference_bounce_limit:
+            pc["maxDepth"] = 10
+        return pc
+
+    # -- VulkanRenderer::render(pushConstants): asynchronous
+    def render(self, pushConstants) -> None:
+        pc = self._pc(pushConstants)
+        _lib.check(self._lib.pt_render(self._h, pc.ctypes.data))
+
+    # -- VulkanRenderer::present(): wait for the frame
+    def present(self) -> None:
+        _lib.check(self._lib.pt_present(self._h))
+
+    # ---- beyond the reference interface ----
+    def setScene(self, scene) -> None:
+        self.updateScene(scene.spheres, scene.ellipsoids, scene.materials, scene.lights, scene.volumes, scene.voxels)
+
+    def resetVoxels(self) -> None:
+        _lib.check(self._lib.pt_reset_voxels(self._h))
+
+    def localRows(self) -> int:
+        return self._lib.pt_local_rows(self._h)
+
+    def readbackRGBA8(self) -> np.ndarray:
+        out = np.empty((self.localRows(), self.width, 4), dtype=np.uint8)
+        _lib.check(self._lib.pt_readback_rgba8(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def readbackF32(self) -> np.ndarray:
+        out = np.empty((self.localRows(), self.width, 4), dtype=np.float32)
+        _lib.check(self._lib.pt_readback_f32(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def renderCounted(self, pushConstants) -> np.ndarray:
+        pc = self._pc(pushConstants)
+        cnt = np.zeros(len(T.COUNTER_NAMES), dtype=np.uint64)
+        _lib.check(self._lib.pt_render_counted(self._h, pc.ctypes.data, cnt.ctypes.data))
+        return cnt
+
+    def setRowBands(self, band_rows: int, band_index: int, band_count: int) -> None:
+        _lib.check(self._lib.pt_set_row_bands(self._h, band_rows, band_index, band_count))
+
+    def assembleBands(self, src_ptr: int, dst_ptr: int, elem_bytes: int, band_rows: int, band_count: int,
+                      stride_rows: int) -> None:
+        _lib.check(self._lib.pt_assemble_bands(self._h, src_ptr, dst_ptr, elem_bytes, band_rows, band_count,
+                                               stride_rows))
+
+    def setOutput(self, rgba8_ptr: Optional[int], f32_ptr: Optional[int] = None) -> None:
+        _lib.check(self._lib.pt_set_output(self._h, rgba8_ptr, f32_ptr))
+
+    def setStream(self, stream_ptr: Optional[int]) -> None:
+        _lib.check(self._lib.pt_set_stream(self._h, stream_ptr))
+
+    def setOption(self, option: int, value: int) -> None:
+        _lib.check(self._lib.pt_set_option(self._h, option, value))
+
+    def timerBegin(self) -> None:
+        _lib.check(self._lib.pt_timer_begin(self._h))
+
+    def timerEnd(self) -> None:
+        _lib.check(self._lib.pt_timer_end(self._h))
+
+    def timerElapsedMs(self) -> float:
+        ms = C.c_float()
+        _lib.check(self._lib.pt_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def deviceInfo(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        _lib.check(self._lib.pt_device_info(self._h, name, 256, C.byref(cu)))
+        return name.value.decode(), cu.value
+
+    def lastLaunch(self):
+        b, t, l = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.pt_last_launch(self._h, C.byref(b), C.byref(t), C.byref(l)))
+        return b.value, t.value, l.value
+
+    def devicePointers(self):
+        return self._lib.pt_device_rgba8(self._h), self._lib.pt_device_f32(self._h)
+
+
+def render_scene(scene, device: int = 0, counted: bool = False, reference_bounce_limit: bool = False):
+    """Convenience: one frame of ``scene`` -> (rgba8, f32[, counters])."""
+    r = HipRenderer()
+    if not r.initialize(scene.width, scene.height, device):
+        raise RuntimeError("HipRenderer.initialize failed")
+    try:
+        r.reference_bounce_limit = reference_bounce_limit
+        r.setScene(scene)
+        pc = scene.push_constants()
+        r.render(pc)
+        r.present()
+        out = (r.readbackRGBA8(), r.readbackF32())
+        if counted:
+            out = out + (r.renderCounted(pc),)
+        return out
+    finally:
+        r.shutdown()
