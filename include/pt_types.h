@@ -119,6 +119,10 @@ enum {
   PT_CNT_ELLIPSOID_TESTS, /* ray-ellipsoid tests, brute force (rays * Ne) */
   PT_CNT_VOXEL_SAMPLES,   /* volume march steps                           */
   PT_CNT_SHADED_HITS,     /* calculateLighting calls                      */
+  PT_CNT_SPHERE_ROOTS,    /* sphere tests with discriminant >= 0 (sqrt taken) */
+  PT_CNT_ELLIPSOID_ROOTS, /* ellipsoid tests with discriminant >= 0        */
+  PT_CNT_WAVE_TRIPS,      /* device only: 4-sphere loop trips over all waves */
+  PT_CNT_WAVE_SLOW_TRIPS, /* device only: trips that left the miss fast path */
   PT_CNT_COUNT
 };
 

@@ -91,6 +91,10 @@ typedef struct {
   uint64_t cnt[PT_CNT_COUNT];
 } Ctx;
 
+/* Per-thread pointer to the {sphere, ellipsoid} root-evaluation counters of
+ * the frame being rendered (NULL inside the single-function probes). */
+static _Thread_local uint64_t *g_roots = 0;
+
 /* ---------- raytrace.comp:99-115 ---------- */
 static v3 rotateByQuaternion(v3 v, v4 q) {
   v3 qxyz = V3(q.x, q.y, q.z);
@@ -129,6 +133,7 @@ static int hitSphere(Ray ray, v3 center, float radius, float tMin, float tMax,
   float c = fmaf(-radius, radius, dot3(oc, oc));
   float discriminant = fmaf(half_b, half_b, -c);
   if (discriminant < 0.0f) return 0;
+  if (g_roots) g_roots[0]++;
   float sqrtDisc = sqrtf(discriminant);
   float t = -half_b - sqrtDisc;
   if (t < tMin || t > tMax) {
@@ -155,6 +160,7 @@ static int hitEllipsoid(Ray ray, v3 center, v3 radii, v4 rotation, float tMin,
   float c = dot3(ocScaled, ocScaled) - 1.0f;
   float discriminant = fmaf(half_b, half_b, -(a * c));
   if (discriminant < 0.0f) return 0;
+  if (g_roots) g_roots[1]++;
   float sqrtDisc = sqrtf(discriminant);
   float t = (-half_b - sqrtDisc) / a;
   if (t < tMin || t > tMax) {
@@ -648,9 +654,11 @@ typedef struct {
 
 static void *worker(void *arg) {
   Job *j = (Job *)arg;
+  g_roots = &j->ctx.cnt[PT_CNT_SPHERE_ROOTS];
   for (int y = j->row_begin + j->tid; y < j->row_end; y += j->nthreads)
     for (int x = 0; x < j->ctx.width; x++)
       renderPixel(&j->ctx, x, y, j->out_f32, j->out_rgba8);
+  g_roots = 0;
   return NULL;
 }
 

@@ -85,15 +85,16 @@ struct PtRenderer {
 
   // scene
   bool sceneValid = false;
+  bool sceneHuge = false; // a sphere with a non-finite or > 1e9 centre/radius: rays take the exact routine
   int numSpheres = 0, numEllipsoids = 0, numMaterials = 0, numLights = 0, numVolumes = 0;
   int numEmSpheres = 0, numEmEllipsoids = 0;
-  DevBuf dSpheres, dSphereMat, dEllipsoids, dEllipsoidMat, dMaterials, dLights, dEmSpheres, dEmEllipsoids, dVoxels;
+  DevBuf dSpheres, dSpherePairs, dSphereMat, dEllipsoids, dEllipsoidMat, dMaterials, dLights, dEmSpheres, dEmEllipsoids, dVoxels;
   bool voxelsUploaded = false;
   size_t voxelBytes = 0;
   PtGPUVolumetricData volume0{};
 
   // output
-  DevBuf dRgba8, dF32, dScratch; // dScratch: tile counter (4 B) + counters (8 x 8 B)
+  DevBuf dRgba8, dF32, dScratch; // dScratch: tile counter (4 B), counters (PT_CNT_COUNT x 8 B) at +64
   void *extRgba8 = nullptr, *extF32 = nullptr;
   bool floatOutput = true;
   int objectSource = 0;
@@ -184,6 +185,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
     P.volMaterial = v.materialIndex;
   }
   P.spheres = (const float4 *)r->dSpheres.p;
+  P.spherePairs = (const float4 *)r->dSpherePairs.p;
   P.sphereMat = (const int *)r->dSphereMat.p;
   P.ellipsoids = (const float4 *)r->dEllipsoids.p;
   P.ellipsoidMat = (const int *)r->dEllipsoidMat.p;
@@ -202,16 +204,19 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
   // Launch geometry: persistent workgroups, 16 waves per CU.  Objects are
   // staged in LDS when they fit (<= 80 KiB: two 512-thread groups per CU;
   // <= 160 KiB: one 1024-thread group); otherwise read from global memory.
-  size_t ldsBytes = ((size_t)P.numSpheres + 4 * (size_t)P.numEllipsoids) * sizeof(float4);
-  bool useLds = ldsBytes <= 160 * 1024;
+  // LDS per workgroup: the object image (if staged) + 1 KiB of queue/result scratch per wave.
+  size_t objBytes = (4 * (size_t)((P.numSpheres + 3) / 4) + 4 * (size_t)P.numEllipsoids) * sizeof(float4);
+  bool useLds = objBytes + 16 * 1024 <= 160 * 1024;
   if (r->objectSource == 1 && !useLds)
     return fail(PT_ERR_INVALID, "pt_render: scene does not fit the 160 KiB LDS (PT_OPT_OBJECT_SOURCE=1)");
   if (r->objectSource == 2) useLds = false;
   int threads, blocksPerCu;
-  if (!useLds) { ldsBytes = 0; threads = 256; blocksPerCu = 4; }
-  else if (ldsBytes <= 40 * 1024) { threads = 256; blocksPerCu = 4; }
-  else if (ldsBytes <= 80 * 1024) { threads = 512; blocksPerCu = 2; }
-  else { threads = 1024; blocksPerCu = 1; }
+  if (!useLds) { objBytes = 0; threads = 256; blocksPerCu = 4; }
+  else if (objBytes <= 32 * 1024) { threads = 256; blocksPerCu = 4; }   // 4 x (32 + 4) KiB
+  else if (objBytes <= 64 * 1024) { threads = 512; blocksPerCu = 2; }   // 2 x (64 + 8) KiB
+  else { threads = 1024; blocksPerCu = 1; }                             // 1 x (<=144 + 16) KiB
+  size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024;
+  P.sceneHuge = r->sceneHuge ? 1 : 0;
   long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
   int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
@@ -224,7 +229,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
       hipLaunchKernelGGL((ptdev::pt_render_kernel<true, true>), grid, block, ldsBytes, r->stream, P);
     } else {
-      hipLaunchKernelGGL((ptdev::pt_render_kernel<true, false>), grid, block, 0, r->stream, P);
+      hipLaunchKernelGGL((ptdev::pt_render_kernel<true, false>), grid, block, ldsBytes, r->stream, P);
     }
   } else {
     if (useLds) {
@@ -232,7 +237,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
       hipLaunchKernelGGL((ptdev::pt_render_kernel<false, true>), grid, block, ldsBytes, r->stream, P);
     } else {
-      hipLaunchKernelGGL((ptdev::pt_render_kernel<false, false>), grid, block, 0, r->stream, P);
+      hipLaunchKernelGGL((ptdev::pt_render_kernel<false, false>), grid, block, ldsBytes, r->stream, P);
     }
   }
   PT_HIP_CHECK(hipGetLastError());
@@ -289,7 +294,7 @@ void pt_destroy(PtRenderer *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dSphereMat, &r->dEllipsoids, &r->dEllipsoidMat, &r->dMaterials, &r->dLights,
+  DevBuf *bufs[] = {&r->dSpheres, &r->dSpherePairs, &r->dSphereMat, &r->dEllipsoids, &r->dEllipsoidMat, &r->dMaterials, &r->dLights,
                     &r->dEmSpheres, &r->dEmEllipsoids, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch};
   for (DevBuf *b : bufs) b->release();
   if (r->evBegin) (void)hipEventDestroy(r->evBegin);
@@ -305,6 +310,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   if (!r) return fail(PT_ERR_INVALID, "pt_update_scene: renderer is null");
   if (num_spheres < 0 || num_ellipsoids < 0 || num_materials < 0 || num_lights < 0 || num_volumes < 0)
     return fail(PT_ERR_INVALID, "pt_update_scene: negative count");
+  if (num_spheres > (1 << 24)) return fail(PT_ERR_INVALID, "pt_update_scene: more than 2^24 spheres");
   if ((num_spheres && !spheres) || (num_ellipsoids && !ellipsoids) || (num_materials && !materials) ||
       (num_lights && !lights) || (num_volumes && !volumes))
     return fail(PT_ERR_INVALID, "pt_update_scene: null array with a non-zero count");
@@ -334,10 +340,25 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   std::vector<float4> hs((size_t)num_spheres);
   std::vector<int> hsm((size_t)num_spheres);
   std::vector<int> emS;
+  bool sceneHuge = false;
   for (int i = 0; i < num_spheres; ++i) {
     hs[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
     hsm[i] = spheres[i].materialIndex;
+    for (float v : {hs[i].x, hs[i].y, hs[i].z, hs[i].w})
+      if (!(std::fabs(v) <= 1.0e9f)) sceneHuge = true;
     if (materials[hsm[i]].transparencyEmissive[1] > 0.0f) emS.push_back(i);
+  }
+  // The intersection loop reads spheres two at a time:
+  //   (cx0, cx1, cy0, cy1) (cz0, cz1, r0, r1)
+  // padded with copies of the last sphere to whole groups of four (the copies
+  // can never win: their index is >= the sphere count).
+  const int nGroups = (num_spheres + 3) / 4;
+  std::vector<float4> hp((size_t)nGroups * 4);
+  for (int p = 0; p < nGroups * 2; ++p) {
+    const float4 &s0 = hs[std::min(2 * p, num_spheres - 1)];
+    const float4 &s1 = hs[std::min(2 * p + 1, num_spheres - 1)];
+    hp[2 * p] = make_float4(s0.x, s1.x, s0.y, s1.y);
+    hp[2 * p + 1] = make_float4(s0.z, s1.z, s0.w, s1.w);
   }
   // Ellipsoids: centre + qw, 1/radii + max radius, -q.xyz, -2 q.xyz.  1/radii is
   // the same IEEE division hitEllipsoid does per test (reference
@@ -363,6 +384,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
 
   int rc;
   if ((rc = upload(r->dSpheres, hs, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dSpherePairs, hp, r->stream)) != PT_OK) return rc;
   if ((rc = upload(r->dSphereMat, hsm, r->stream)) != PT_OK) return rc;
   if ((rc = upload(r->dEllipsoids, he, r->stream)) != PT_OK) return rc;
   if ((rc = upload(r->dEllipsoidMat, hem, r->stream)) != PT_OK) return rc;
@@ -392,6 +414,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   // The host vectors die at return: finish the copies first.
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
 
+  r->sceneHuge = sceneHuge;
   r->numSpheres = num_spheres;
   r->numEllipsoids = num_ellipsoids;
   r->numMaterials = num_materials;

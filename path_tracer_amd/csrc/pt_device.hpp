@@ -47,12 +47,15 @@ struct FrameParams {
   int numEmSpheres, numEmEllipsoids;
   int maxBounces;
   int tilesX, numTiles;
+  int sceneHuge;         // 1: some sphere has a non-finite or > 1e9 coordinate (no fast path)
   // volume 0 (raytrace.comp:538-550); boxMin/boxMax/extent precomputed
   float volPos[3], v0[3], v1[3], boxMin[3], boxMax[3], extent[3];
   int res[3];
   int volMaterial;
   // scene, SoA
-  const float4 *spheres;    // (cx, cy, cz, r)
+  const float4 *spheres;    // (cx, cy, cz, r), one per sphere
+  const float4 *spherePairs; // 2 float4 per pair of spheres: (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1),
+                             // padded with copies of the last sphere to a multiple of 4 spheres
   const int *sphereMat;
   const float4 *ellipsoids; // 4 per ellipsoid: (c, qw) (1/radii, maxRadius) (-q.xyz, 0) (-2q.xyz, 0)
   const int *ellipsoidMat;
@@ -99,19 +102,17 @@ __device__ __forceinline__ float glmin(float x, float y) { return (y < x) ? y : 
 __device__ __forceinline__ float glclamp(float x, float lo, float hi) { return glmin(glmax(x, lo), hi); }
 __device__ __forceinline__ float glfract(float x) { return x - __builtin_floorf(x); }
 
+// Two-wide float math: one v_pk_* instruction works on two spheres at once.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // rotateByQuaternion with q.xyz and 2*q.xyz supplied (raytrace.comp:99-108):
 // t = 2*cross(q, v) == cross(2q, v) exactly; v' = (v + qw*t) + cross(q, t)
 __device__ __forceinline__ V3 rotate_q(V3 v, V3 q, V3 q2, float qw) {
   V3 t = cross3(q2, v);
   return add3(madd3(v, qw, t), cross3(q, t));
 }
-
-struct Ellipsoid {
-  V3 c; float qw;
-  V3 invR; float maxR;
-  V3 nq;   // -q.xyz  (the conjugate's vector part, raytrace.comp:111-115)
-  V3 nq2;  // -2*q.xyz
-};
 
 // ---- surface shaders (compiled-in; index = position in the sorted path list + 1) ----
 
@@ -160,20 +161,29 @@ enum : int {
 
 template <bool COUNT, bool LDS_OBJECTS>
 __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
-  extern __shared__ float4 s_obj[]; // spheres, then 4 float4 per ellipsoid
+  // LDS image: sphere pairs (2 float4 per pair: (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1)),
+  // padded to whole groups of 4 spheres, then 4 float4 per ellipsoid.
+  extern __shared__ float4 s_obj[];
   const int Ns = P.numSpheres, Ne = P.numEllipsoids;
+  const int nGroups = (Ns + 3) >> 2;  // groups of 4 spheres = 4 float4
+  const int ellBase = 4 * nGroups;
   if (LDS_OBJECTS) {
-    for (int i = threadIdx.x; i < Ns; i += blockDim.x) s_obj[i] = P.spheres[i];
-    for (int i = threadIdx.x; i < 4 * Ne; i += blockDim.x) s_obj[Ns + i] = P.ellipsoids[i];
+    for (int i = threadIdx.x; i < 4 * nGroups; i += blockDim.x) s_obj[i] = P.spherePairs[i];
+    for (int i = threadIdx.x; i < 4 * Ne; i += blockDim.x) s_obj[ellBase + i] = P.ellipsoids[i];
     __syncthreads();
   }
-  const float4 *__restrict__ g_sph = P.spheres;
+  const float4 *__restrict__ g_pairs = P.spherePairs;
   const float4 *__restrict__ g_ell = P.ellipsoids;
-#define PT_SPH(i) (LDS_OBJECTS ? s_obj[(i)] : g_sph[(i)])
-#define PT_ELL(j, k) (LDS_OBJECTS ? s_obj[Ns + 4 * (j) + (k)] : g_ell[4 * (j) + (k)])
+#define PT_PAIR(i) (LDS_OBJECTS ? s_obj[(i)] : g_pairs[(i)])
+#define PT_ELL(j, k) (LDS_OBJECTS ? s_obj[ellBase + 4 * (j) + (k)] : g_ell[4 * (j) + (k)])
 
   const int lane = threadIdx.x & 63;
   const unsigned long long laneMaskLt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // per-wave scratch behind the object image: 128-entry candidate ring + 64 result slots (1 KiB)
+  const int objFloat4s = LDS_OBJECTS ? (4 * nGroups + 4 * Ne) : 0;
+  float4 *const w_area = s_obj + objFloat4s + 64 * (int)(threadIdx.x >> 6);
+  unsigned int *const w_queue = (unsigned int *)w_area;
+  unsigned long long *const w_slot = (unsigned long long *)(w_area + 32);
 
   // wave-uniform tile pool
   int poolNext = 0, poolEnd = 0;
@@ -188,7 +198,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   V3 fin = mk3(0, 0, 0);                       // finalColor
   // ray in flight
   V3 rO = mk3(0, 0, 0), rD = mk3(0, 0, 1);
-  float rTmin = kEpsilon, rTmax = -1.0f;
+  float rTmax = -1.0f; // tMin is EPSILON for every ray the shader casts
   // hit being shaded
   V3 hitP = mk3(0, 0, 0), hitN = mk3(0, 0, 1), viewDir = mk3(0, 0, 1);
   int hitMat = 0;
@@ -197,6 +207,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   int k = 0;                 // light index or emissive-list cursor
 
   unsigned int cRays = 0, cPath = 0, cLight = 0, cEmis = 0, cShaded = 0, cVoxel = 0;
+  unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
+  unsigned int cGroups = 0, cSlow = 0;  // wave-level: 4-sphere trips, trips that left the fast path
 
   for (;;) {
     // ------------------------------------------------------------------
@@ -238,7 +250,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           fin = mk3(0, 0, 0);
           thr = 1.0f;
           bounce = 0;
-          rO = curO; rD = curD; rTmin = kEpsilon; rTmax = kMaxDistance;
+          rO = curO; rD = curD; rTmax = kMaxDistance;
           state = ST_PATH;
           if (COUNT) cPath++;
         }
@@ -249,58 +261,197 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     if (__ballot(state != ST_IDLE) == 0ull) break;
 
     // ------------------------------------------------------------------
-    // 2. traceRay for every live lane (raytrace.comp:212-241): wave-uniform
-    //    loop over the objects; bestIdx < Ns is a sphere, else an ellipsoid
+    // 2. traceRay for every live lane (raytrace.comp:212-241); bestIdx < Ns is
+    //    a sphere, else an ellipsoid.
+    //
+    //    Spheres.  The wave-uniform loop only computes discriminants (two
+    //    spheres per packed instruction) and tests their sign.  A lane whose
+    //    discriminant is non-negative appends (lane, sphere) to the wave's LDS
+    //    queue; whenever 64 entries are waiting the whole wave evaluates them,
+    //    one entry per lane: exact roots, then a 64-bit LDS atomic-min per
+    //    owning lane on (t, ~index).  For finite rays hitSphere's result does
+    //    not depend on the order of the spheres (smallest accepted t wins, an
+    //    exact tie goes to the later sphere), so the deferred evaluation gives
+    //    the same winner as the shader's sequential loop.  Rays with
+    //    non-finite or huge coordinates, where NaNs make the shader's loop
+    //    order-dependent, take the exact routine below instead.
     // ------------------------------------------------------------------
+    const bool live = state != ST_IDLE;
     float bestT = rTmax;
     int bestIdx = -1;
-    if (state != ST_IDLE) {
-      if (COUNT) cRays++;
-      const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
-      const float tMin = rTmin;
-      // hitSphere (raytrace.comp:142-168), point/normal deferred to the winner
-#define PT_SPHERE_DISC(S, HB, DISC)                                              \
+    {
+      const float tMin = kEpsilon; // every ray of the shader uses tMin = EPSILON
+      const float kBig = 1.0e9f;   // |coordinates| up to here cannot overflow the discriminant
+      const bool finiteRay = __builtin_fabsf(rO.x) <= kBig && __builtin_fabsf(rO.y) <= kBig &&
+                             __builtin_fabsf(rO.z) <= kBig && __builtin_fabsf(rD.x) <= kBig &&
+                             __builtin_fabsf(rD.y) <= kBig && __builtin_fabsf(rD.z) <= kBig;
+      const bool fastLane = live && finiteRay && P.sceneHuge == 0;
+      const bool special = live && !fastLane;
+      if (COUNT && live) cRays++;
+      // lanes without a finite ray get one that can never produce a candidate
+      const float ox = fastLane ? rO.x : 4.0e9f, oy = fastLane ? rO.y : 4.0e9f, oz = fastLane ? rO.z : 4.0e9f;
+      const float dx = fastLane ? rD.x : 0.0f, dy = fastLane ? rD.y : 0.0f, dz = fastLane ? rD.z : 0.0f;
+
+      // slot[lane] = (bits(t) << 32) | ~(index + 1) of the best accepted sphere so
+      // far; t >= tMin > 0, so unsigned order on the bits is float order, and on
+      // equal t the larger index has the smaller key.  Start at (tMax, none):
+      // acceptance is t <= tMax.
+      {
+        unsigned long long init = 0ull; // tMax < tMin: nothing can be accepted
+        if (rTmax >= tMin) init = ((unsigned long long)__float_as_uint(rTmax) << 32) | 0xFFFFFFFFull;
+        w_slot[lane] = init;
+      }
+      int qHead = 0, qTail = 0; // ring of 128 entries, wave-uniform cursors
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+      // Evaluate n <= 64 queued (lane, sphere) candidates, one per lane.
+      auto drain = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned int e = w_queue[(qHead + lane) & 127];
+        const bool on = lane < n;
+        const int owner = on ? (int)(e & 63u) : lane;
+        const int idx = on ? (int)(e >> 6) : 0;
+        const float eox = __shfl(ox, owner), eoy = __shfl(oy, owner), eoz = __shfl(oz, owner);
+        const float edx = __shfl(dx, owner), edy = __shfl(dy, owner), edz = __shfl(dz, owner);
+        float cx, cy, cz, rr;
+        if (LDS_OBJECTS) {
+          const float *sf = (const float *)s_obj;
+          const int f = 8 * (idx >> 1) + (idx & 1);
+          cx = sf[f]; cy = sf[f + 2]; cz = sf[f + 4]; rr = sf[f + 6];
+        } else {
+          const float4 sp = P.spheres[idx];
+          cx = sp.x; cy = sp.y; cz = sp.z; rr = sp.w;
+        }
+        // hitSphere (raytrace.comp:142-159), same operations as the packed loop
+        const float ocx = eox - cx, ocy = eoy - cy, ocz = eoz - cz;
+        const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
+        const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+        const float cc = __builtin_fmaf(-rr, rr, dd);
+        const float disc = __builtin_fmaf(hb, hb, -cc);
+        const float sq = __builtin_sqrtf(disc);
+        float t = -hb - sq;
+        if (t < tMin) t = -hb + sq;
+        // accepted iff tMin <= t <= closest-so-far; the atomic min applies the upper bound
+        if (on && !(t < tMin)) {
+          const unsigned long long key =
+              ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(~((unsigned int)idx + 1u));
+          atomicMin(&w_slot[owner], key);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      };
+
+      const f2 OX = mk2(ox, ox), OY = mk2(oy, oy), OZ = mk2(oz, oz);
+      const f2 DX = mk2(dx, dx), DY = mk2(dy, dy), DZ = mk2(dz, dz);
+#define PT_PAIR_DISC(A, B, DISC)                                                 \
   {                                                                              \
-    const float ocx = ox - S.x, ocy = oy - S.y, ocz = oz - S.z;                  \
-    HB = __builtin_fmaf(ocz, dz, __builtin_fmaf(ocy, dy, ocx * dx));             \
-    const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)); \
-    const float cc = __builtin_fmaf(-S.w, S.w, dd);                              \
-    DISC = __builtin_fmaf(HB, HB, -cc);                                          \
+    const f2 ocx = OX - mk2(A.x, A.y), ocy = OY - mk2(A.z, A.w), ocz = OZ - mk2(B.x, B.y); \
+    const f2 rr = mk2(B.z, B.w);                                                 \
+    const f2 hb = fma2(ocz, DZ, fma2(ocy, DY, ocx * DX));                        \
+    const f2 dd = fma2(ocz, ocz, fma2(ocy, ocy, ocx * ocx));                     \
+    const f2 cc = fma2(-rr, rr, dd);                                             \
+    DISC = fma2(hb, hb, -cc);                                                    \
   }
-#define PT_SPHERE_ACCEPT(IDX, HB, DISC)                                          \
-  if (!(DISC < 0.0f)) {                                                          \
-    const float sq = __builtin_sqrtf(DISC);                                      \
-    float t = -HB - sq;                                                          \
-    bool ok = !(t < tMin || t > bestT);                                          \
-    if (!ok) {                                                                   \
-      t = -HB + sq;                                                              \
-      ok = !(t < tMin || t > bestT);                                             \
+#define PT_ENQUEUE(IDX, DISC)                                                    \
+  {                                                                              \
+    const bool c_ = (DISC >= 0.0f) && (IDX) < Ns;                                \
+    const unsigned long long m_ = __ballot(c_);                                  \
+    if (m_ != 0ull) {                                                            \
+      const int pre_ = __popcll(m_ & laneMaskLt);                                \
+      if (c_) {                                                                  \
+        w_queue[(qTail + pre_) & 127] = (unsigned int)lane | ((unsigned int)(IDX) << 6); \
+        if (COUNT) cRoots++;                                                     \
+      }                                                                          \
+      qTail += __popcll(m_);                                                     \
+      if (qTail - qHead >= 64) { drain(64); qHead += 64; }                       \
     }                                                                            \
-    if (ok) { bestT = t; bestIdx = (IDX); }                                      \
   }
-      int i = 0;
-      for (; i + 4 <= Ns; i += 4) {
-        const float4 s0 = PT_SPH(i), s1 = PT_SPH(i + 1), s2 = PT_SPH(i + 2), s3 = PT_SPH(i + 3);
-        float hb0, hb1, hb2, hb3, d0, d1, d2, d3;
-        PT_SPHERE_DISC(s0, hb0, d0)
-        PT_SPHERE_DISC(s1, hb1, d1)
-        PT_SPHERE_DISC(s2, hb2, d2)
-        PT_SPHERE_DISC(s3, hb3, d3)
-        const bool any = !(d0 < 0.0f) | !(d1 < 0.0f) | !(d2 < 0.0f) | !(d3 < 0.0f);
-        if (__ballot(any) != 0ull) {
-          PT_SPHERE_ACCEPT(i, hb0, d0)
-          PT_SPHERE_ACCEPT(i + 1, hb1, d1)
-          PT_SPHERE_ACCEPT(i + 2, hb2, d2)
-          PT_SPHERE_ACCEPT(i + 3, hb3, d3)
+      if (__ballot(fastLane) != 0ull) {
+        for (int g = 0; g < nGroups; ++g) {
+          const float4 a0 = PT_PAIR(4 * g), b0 = PT_PAIR(4 * g + 1), a1 = PT_PAIR(4 * g + 2), b1 = PT_PAIR(4 * g + 3);
+          f2 d0, d1;
+          PT_PAIR_DISC(a0, b0, d0)
+          PT_PAIR_DISC(a1, b1, d1)
+          // finite rays and a finite scene give finite discriminants (no NaN to lose in max)
+          const float m = __builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y));
+          if (COUNT) cGroups++;
+          if (__ballot(m >= 0.0f) != 0ull) {
+            if (COUNT) cSlow++;
+            PT_ENQUEUE(4 * g, d0.x)
+            PT_ENQUEUE(4 * g + 1, d0.y)
+            PT_ENQUEUE(4 * g + 2, d1.x)
+            PT_ENQUEUE(4 * g + 3, d1.y)
+          }
+        }
+        if (qTail > qHead) { drain(qTail - qHead); qHead = qTail; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long kbest = w_slot[lane];
+        const unsigned int widx = ~(unsigned int)kbest - 1u; // none -> 0xFFFFFFFF
+        if (fastLane && widx < (unsigned int)Ns) {
+          bestT = __uint_as_float((unsigned int)(kbest >> 32));
+          bestIdx = (int)widx;
         }
       }
-      for (; i < Ns; ++i) {
-        const float4 s0 = PT_SPH(i);
-        float hb0, d0;
-        PT_SPHERE_DISC(s0, hb0, d0)
-        if (__ballot(!(d0 < 0.0f)) != 0ull) { PT_SPHERE_ACCEPT(i, hb0, d0) }
+
+      // Exact routine for the few rays the fast path must not take: the 64
+      // lanes each take one sphere of a chunk and the shader's sequential
+      // acceptance (including its NaN behaviour: a NaN t is accepted and then
+      // voids the upper bound for the next sphere) is reproduced chunk by chunk.
+      unsigned long long todo = __ballot(special);
+      while (todo != 0ull) {
+        const int owner = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const float eox = __shfl(rO.x, owner), eoy = __shfl(rO.y, owner), eoz = __shfl(rO.z, owner);
+        const float edx = __shfl(rD.x, owner), edy = __shfl(rD.y, owner), edz = __shfl(rD.z, owner);
+        float C = __shfl(rTmax, owner); // closestT
+        int win = -1;
+        unsigned int roots = 0;
+        for (int base = 0; base < Ns; base += 64) {
+          const int j = base + lane;
+          const bool inb = j < Ns;
+          const float4 sp = P.spheres[inb ? j : 0];
+          const float ocx = eox - sp.x, ocy = eoy - sp.y, ocz = eoz - sp.z;
+          const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
+          const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+          const float cc = __builtin_fmaf(-sp.w, sp.w, dd);
+          const float disc = __builtin_fmaf(hb, hb, -cc);
+          const bool root = inb && !(disc < 0.0f);
+          const float sq = __builtin_sqrtf(disc);
+          const float t0 = -hb - sq, t1 = -hb + sq;
+          // a NaN root passes both range tests of hitSphere whatever closestT is
+          const bool nanacc = root && ((t0 != t0) || ((t0 < tMin) && (t1 != t1)));
+          float v = t0;
+          bool valid = root && !nanacc;
+          if (t0 < tMin) { v = t1; valid = valid && !(t1 < tMin); }
+          if (COUNT) roots += (unsigned int)__popcll(__ballot(root));
+          const unsigned long long nm = __ballot(nanacc);
+          if (nm != 0ull) {
+            const int kl = 63 - (int)__builtin_clzll(nm);
+            C = __builtin_nanf("");
+            win = base + kl;
+            valid = valid && lane > kl;
+          }
+          // accepted iff !(v > closestT); with closestT = NaN every valid root is
+          const bool cand = valid && !(v > C);
+          if (__ballot(cand) != 0ull) {
+            float mn = cand ? v : __builtin_inff();
+            for (int off = 32; off > 0; off >>= 1) mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
+            const unsigned long long em = __ballot(cand && v == mn);
+            C = mn;
+            win = base + 63 - (int)__builtin_clzll(em);
+          }
+        }
+        if (lane == owner) {
+          bestT = C;
+          bestIdx = win;
+          if (COUNT) cRoots += roots;
+        }
       }
-      // hitEllipsoid (raytrace.comp:171-210)
+    }
+
+    // hitEllipsoid (raytrace.comp:171-210), after the spheres as in traceRay
+    if (live) {
+      const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
+      const float tMin = kEpsilon;
       for (int j = 0; j < Ne; ++j) {
         const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
         const V3 nq = xyz(e2), nq2 = xyz(e3);
@@ -314,6 +465,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float disc = __builtin_fmaf(hb, hb, -(a * c));
         if (__ballot(!(disc < 0.0f)) != 0ull) {
           if (!(disc < 0.0f)) {
+            if (COUNT) cERoots++;
             const float sq = __builtin_sqrtf(disc);
             float t = (-hb - sq) / a;
             bool ok = !(t < tMin || t > bestT);
@@ -467,7 +619,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           // hit record of the winner
           hitP = madd3(curO, bestT, curD);
           if (bestIdx < Ns) { // hitSphere :161-165
-            const float4 s = PT_SPH(bestIdx);
+            const float4 s = P.spheres[bestIdx];
             hitN = scale3(sub3(hitP, xyz(s)), 1.0f / s.w);
             hitMat = P.sphereMat[bestIdx];
           } else { // hitEllipsoid :198-207
@@ -520,7 +672,6 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const float distToLight = length3(lightVec);
             rO = hitP;
             rD = div3s(lightVec, distToLight);
-            rTmin = kEpsilon;
             rTmax = distToLight;
             state = (step == GO_NEXT_LIGHT) ? ST_LIGHT : ST_TOON_LIGHT;
             if (COUNT) cLight++;
@@ -543,7 +694,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           while (k < P.numEmSpheres) {
             const int si = P.emSpheres[k];
             if (si >= Ns) { k = P.numEmSpheres; break; }
-            const float4 s = PT_SPH(si);
+            const float4 s = P.spheres[si];
             const int mi = P.sphereMat[si];
             const float4 sm0 = P.materials[5 * mi];
             const float4 sm2 = P.materials[5 * mi + 2];
@@ -560,8 +711,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                 emissiveColor = rainbow_emissive(approximateHitPoint, sphereEmissive, P.time);
               } else if (sphereShaderIndex == 2) {
                 // toon keeps result.emissive = surfaceColor * emissiveStrength (toon.glsl:45-47);
-                // its light loop only feeds result.color, which this caller drops
+                // its light loop only feeds result.color, which this caller drops, so the
+                // shadow rays it would issue are elided (but still counted as issued)
                 emissiveColor = scale3(xyz(sm0), sphereEmissive);
+                if (COUNT) { cLight += (unsigned int)P.numLights; cRays += (unsigned int)P.numLights; }
               } else {
                 emissiveColor = mk3(0, 0, 0);
               }
@@ -572,8 +725,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               if (alignment > 0.0f) {
                 rO = madd3(hitP, kEpsilon, hitN);
                 rD = dirToSphere;
-                rTmin = kEpsilon;
-                rTmax = (distToSphere - s.w) - kEpsilon;
+                    rTmax = (distToSphere - s.w) - kEpsilon;
                 const float attenuation =
                     sphereEmissive / ((1.0f + 0.5f * distToSphere) + (0.1f * distToSphere) * distToSphere);
                 pending = scale3(scale3(emissiveColor, alignment), attenuation);
@@ -604,8 +756,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             if (alignment > 0.0f) {
               rO = madd3(hitP, kEpsilon, hitN);
               rD = dirE;
-              rTmin = kEpsilon;
-              rTmax = (distE - e1.w) - kEpsilon;
+                rTmax = (distE - e1.w) - kEpsilon;
               const float attenuation = em2.y / ((1.0f + 0.5f * distE) + (0.1f * distE) * distE);
               pending = scale3(scale3(xyz(em0), alignment), attenuation);
               state = ST_EM_ELLIPSOID;
@@ -646,7 +797,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             bounce++;
             // loop head of traceIterative (:605-606)
             if (bounce < P.maxBounces && !(length3(mk3(thr, thr, thr)) < 0.001f)) {
-              rO = curO; rD = curD; rTmin = kEpsilon; rTmax = kMaxDistance;
+              rO = curO; rD = curD; rTmax = kMaxDistance;
               state = ST_PATH;
               if (COUNT) cPath++;
               step = GO_EMITTED;
@@ -672,22 +823,33 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 
   if (COUNT) {
     // wave reduction, then one atomic per counter per wave
-    unsigned long long v[8];
+    unsigned long long v[12];
     v[0] = cRays; v[1] = cPath; v[2] = cLight; v[3] = cEmis;
     v[4] = (unsigned long long)cRays * (unsigned long long)(Ns > 0 ? Ns : 0);
     v[5] = (unsigned long long)cRays * (unsigned long long)(Ne > 0 ? Ne : 0);
-    v[6] = cVoxel; v[7] = cShaded;
+    v[6] = cVoxel; v[7] = cShaded; v[8] = cRoots; v[9] = cERoots;
+    // wave-level counts: every live lane of a wave saw the same trips, so take lane-max, not the sum
+    v[10] = 0; v[11] = 0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 10; ++c) {
       unsigned long long x = v[c];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0) atomicAdd(&P.counters[c], x);
     }
+    {
+      unsigned int g = cGroups, sl = cSlow;
+      for (int off = 32; off > 0; off >>= 1) {
+        unsigned int og = __shfl_down(g, off, 64), os = __shfl_down(sl, off, 64);
+        g = g > og ? g : og;
+        sl = sl > os ? sl : os;
+      }
+      if (lane == 0) { atomicAdd(&P.counters[10], (unsigned long long)g); atomicAdd(&P.counters[11], (unsigned long long)sl); }
+    }
   }
-#undef PT_SPH
+#undef PT_PAIR
 #undef PT_ELL
-#undef PT_SPHERE_DISC
-#undef PT_SPHERE_ACCEPT
+#undef PT_PAIR_DISC
+#undef PT_ENQUEUE
 }
 
 // De-interleave the compact band-major frames of `bandCount` renderers into

@@ -86,7 +86,12 @@ COUNTER_NAMES = (
     "ellipsoid_tests",
     "voxel_samples",
     "shaded_hits",
+    "sphere_roots",
+    "ellipsoid_roots",
+    "wave_trips",       # device only
+    "wave_slow_trips",  # device only
 )
+N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 
 # Compiled-in surface shaders, keyed by the path string the reference's
 # ShaderCompiler would have seen (reference src/ShaderCompiler.cpp:131-185:

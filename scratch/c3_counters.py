@@ -1,0 +1,16 @@
+import sys, time, numpy as np
+sys.path.insert(0,'.')
+from path_tracer_amd import scenes, HipRenderer
+from path_tracer_amd import types as T
+name = sys.argv[1] if len(sys.argv)>1 else 'c3'
+sc = {'c3':scenes.config3,'c2':scenes.config2}[name]()
+r = HipRenderer(); assert r.initialize(sc.width, sc.height)
+r.setOption(1,0); r.setScene(sc); pc = sc.push_constants()
+cnt = r.renderCounted(pc)
+print(dict(zip(T.COUNTER_NAMES,[int(x) for x in cnt])))
+ns = len(sc.spheres); groups=(ns+3)//4
+wave_passes_min = cnt[0]/64
+print('rays/px', cnt[0]/(sc.width*sc.height), 'ideal trips', wave_passes_min*groups, 'actual trips', int(cnt[10]), 'lane util', wave_passes_min*groups/cnt[10], 'slow frac', cnt[11]/cnt[10], 'roots/ray', cnt[8]/cnt[0])
+for i in range(3):
+    r.timerBegin(); r.render(pc); r.timerEnd(); print('ms', r.timerElapsedMs())
+print(r.lastLaunch())
