@@ -64,55 +64,69 @@ def build_scene(name: str, scale: float = 1.0):
 
 
 class Runner:
-    """One renderer on this rank's GPU, optionally band-split with an RCCL gather."""
+    """One renderer on this rank's GPU, optionally band-split with a gather to rank 0.
 
-    def __init__(self, scene, rank: int, world: int, device: int, torch_mod=None, dist=None):
+    backend "nccl": the compact frame is rendered straight into a torch CUDA
+    tensor on torch's stream, gathered over RCCL and de-interleaved by a device
+    kernel.  backend "gloo" (rehearsal on a box with fewer GPUs than ranks): the
+    compact frame is read back and gathered through host memory.
+    """
+
+    def __init__(self, scene, rank: int, world: int, device: int, torch_mod=None, dist=None, backend="nccl"):
         from path_tracer_amd import HipRenderer
+        from path_tracer_amd.distributed import BandGather
 
         self.scene, self.rank, self.world = scene, rank, world
-        self.torch, self.dist = torch_mod, dist
+        self.torch, self.dist, self.backend = torch_mod, dist, backend
         self.r = HipRenderer()
         if not self.r.initialize(scene.width, scene.height, device):
             raise SystemExit("renderer initialisation failed")
         self.r.setOption(1, 0)  # PT_OPT_FLOAT_OUTPUT off: the benchmark keeps the rgba8 frame only
         self.r.setScene(scene)
         self.pc = scene.push_constants()
-        self.local = self.gathered = self.frame = None
+        self.bg = self.frame = None
         if world > 1:
             t = torch_mod
             self.r.setRowBands(BAND_ROWS, rank, world)
-            n_bands = (scene.height + BAND_ROWS - 1) // BAND_ROWS
-            self.stride_rows = ((n_bands + world - 1) // world) * BAND_ROWS
-            self.local = t.zeros((self.stride_rows, scene.width, 4), dtype=t.uint8, device=f"cuda:{device}")
-            self.r.setStream(t.cuda.current_stream().cuda_stream)
-            self.r.setOutput(self.local.data_ptr(), None)
-            if rank == 0:
-                self.gathered = t.zeros((world, self.stride_rows, scene.width, 4), dtype=t.uint8,
-                                        device=f"cuda:{device}")
-                self.frame = t.zeros((scene.height, scene.width, 4), dtype=t.uint8, device=f"cuda:{device}")
+            dev = f"cuda:{device}" if backend == "nccl" else "cpu"
+            self.bg = BandGather(t, dist, scene.width, scene.height, rank, world, dev, band_rows=BAND_ROWS)
+            assert self.bg.local_rows == self.r.localRows()
+            if backend == "nccl":
+                self.r.setStream(t.cuda.current_stream().cuda_stream)
+                self.r.setOutput(self.bg.local.data_ptr(), None)
+                if rank == 0:
+                    self.frame = t.zeros((scene.height, scene.width, 4), dtype=t.uint8, device=dev)
+
+    def _reduce(self, values, op="sum"):
+        if self.world == 1:
+            return values
+        t = self.torch
+        dev = self.bg.local.device
+        x = t.tensor(values, dtype=t.float64, device=dev)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+        return x.cpu().numpy()
 
     def counters(self):
-        cnt = self.r.renderCounted(self.pc).astype(np.float64)
-        if self.world > 1:
-            t = self.torch
-            c = t.tensor(cnt, dtype=t.float64, device=self.local.device)
-            self.dist.all_reduce(c)
-            cnt = c.cpu().numpy()
-        return cnt
+        return self._reduce(self.r.renderCounted(self.pc).astype(np.float64))
 
     def step(self):
         self.r.render(self.pc)
         if self.world > 1:
-            if self.rank == 0:
-                self.dist.gather(self.local, list(self.gathered.unbind(0)), dst=0)
-                self.r.assembleBands(self.gathered.data_ptr(), self.frame.data_ptr(), 4, BAND_ROWS, self.world,
-                                     self.stride_rows)
+            if self.backend == "nccl":
+                self.bg.gather()
+                if self.rank == 0:
+                    self.r.assembleBands(self.bg.gathered.data_ptr(), self.frame.data_ptr(), 4, BAND_ROWS, self.world,
+                                         self.bg.stride_rows)
             else:
-                self.dist.gather(self.local, None, dst=0)
+                part = self.r.readbackRGBA8()
+                self.bg.local[:part.shape[0]] = self.torch.from_numpy(part)
+                self.bg.gather()
+                if self.rank == 0:
+                    self.frame = self.bg.assemble_host()
 
     def sync(self):
         self.r.present()
-        if self.world > 1:
+        if self.world > 1 and self.backend == "nccl":
             self.torch.cuda.synchronize()
 
     def barrier(self):
@@ -136,12 +150,16 @@ class Runner:
         self.sync()
         dt = time.perf_counter() - t0
         ev_ms = self.r.timerElapsedMs()
-        if self.world > 1:
-            t = self.torch
-            x = t.tensor([dt], dtype=t.float64, device=self.local.device)
-            self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX)
-            dt = float(x.item())
+        dt = float(self._reduce([dt], "max")[0])
         return dt, ev_ms
+
+    def final_frame(self):
+        """Rank 0: the assembled (or whole) rgba8 frame as numpy."""
+        if self.world == 1:
+            return self.r.readbackRGBA8()
+        if self.rank != 0:
+            return None
+        return self.frame.cpu().numpy() if self.backend == "nccl" else self.frame
 
     def close(self):
         self.r.shutdown()
@@ -200,6 +218,10 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (testing only; 1.0 = the named config)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4 side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (gloo = host-memory rehearsal)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
+    ap.add_argument("--check", action="store_true", help="rank 0 verifies the final frame against a single-GPU render")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,17 +233,31 @@ def main():
         import torch
         import torch.distributed as dist_mod
 
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.same_device:
+            local_rank = 0
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist_mod.init_process_group("gloo")
         torch_mod, dist = torch, dist_mod
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     n_gpus = world
 
     scene = build_scene(args.workload, args.scale)
-    run = Runner(scene, rank, world, local_rank, torch_mod, dist)
+    run = Runner(scene, rank, world, local_rank, torch_mod, dist, args.backend)
     cnt = run.counters()
     dt, ev_ms = run.timed(args.steps, args.warmup)
+    check = None
+    if args.check and world > 1:
+        frame = run.final_frame()
+        if rank == 0:
+            solo = Runner(scene, 0, 1, local_rank)
+            solo.step()
+            solo.sync()
+            check = bool(np.array_equal(frame, solo.final_frame()))
+            solo.close()
     ms_per_step = dt / args.steps * 1e3
     kernel_ms = ev_ms / args.steps
     dev_name, cus = run.r.deviceInfo()
@@ -249,6 +285,8 @@ def main():
                        "launch": {"blocks": launch[0], "threads": launch[1], "lds_bytes": launch[2]}},
             "roofline": roofline_for(cnt / max(n_gpus, 1), kernel_ms) if n_gpus == 1 else None,
         }
+        if check is not None:
+            result["config"]["gathered_frame_equals_single_gpu_frame"] = check
         if n_gpus > 1:
             result["roofline"] = roofline_for(cnt / n_gpus, kernel_ms)
             result["roofline"]["note"] += "; per-rank share, event time includes the gather"

@@ -1,0 +1,196 @@
+// HipRenderer.h — the renderer boundary of the scene API on MI355X.
+//
+// Same public interface as the reference's class VulkanRenderer (reference
+// include/VulkanRenderer.h:73-97) and the same record types (reference
+// include/VulkanRenderer.h:16-71); a program written against the reference
+// compiles against this header after replacing the type name.  Everything
+// forwards to the C-ABI of pt_hip.h (libpt_hip.so), so no HIP header is needed
+// to use it.
+//
+// Differences, all forced by leaving Vulkan/SDL behind:
+//   * initialize() takes an opaque window pointer that is ignored (there is
+//     no swapchain); the frame is read back with readbackRGBA8()/readbackFloat()
+//     or written with writePPM().
+//   * present() waits for the frame instead of blitting it.
+//   * render() honours PushConstants::maxDepth unless referenceBounceLimit is
+//     set, in which case it renders 10 bounces like the reference shader, which
+//     ignores the field (reference shaders/raytrace.comp:603).
+//   * getOutputImage() returns the device pointer of the rgba8 frame.
+#ifndef PATH_TRACER_HIP_RENDERER_H
+#define PATH_TRACER_HIP_RENDERER_H
+
+#include "../pt_hip.h"
+#include "Ellipsoid.h"
+#include "glm_compat.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <iostream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct GPUSphere {
+  glm::vec3 center;
+  float radius;
+  glm::vec3 color;
+  int materialIndex;
+};
+
+// GPUEllipsoid is defined in Ellipsoid.h
+
+struct GPUMaterial {
+  glm::vec4 colorAndAmbient;      // color.xyz, ambient.w
+  glm::vec4 diffuseSpecularShiny; // diffuse.x, specular.y, shininess.z, reflectivity.w
+  glm::vec4 transparencyEmissive; // transparency.x, emissiveStrength.y, shaderFunctionIndex.z (as float), pad.w
+  glm::vec4 emissive;             // emissive.xyz, pad.w
+  glm::vec4 scatterAndAbsorption; // scatterColor.xyz, absorptionCoeff.w
+};
+
+struct GPULight {
+  glm::vec3 position;
+  float intensity;
+  glm::vec3 color;
+  float padding;
+};
+
+struct GPUVolumetricData {
+  glm::vec3 position;
+  float scale;
+  glm::vec3 v0;
+  int resolution_x;
+  glm::vec3 v1;
+  int resolution_y;
+  int resolution_z;
+  int materialIndex;
+  int padding[2];
+};
+
+struct PushConstants {
+  glm::mat4 cameraMatrix;  // offset 0   (not used by the ray loop)
+  glm::vec3 cameraPos;     // offset 64
+  float time;              // offset 76  (milliseconds)
+  int numSpheres;          // offset 80
+  int numEllipsoids;       // offset 84
+  int numLights;           // offset 88
+  int numVolumes;          // offset 92
+  int maxDepth;            // offset 96
+  int padding1;
+  int padding2;
+  int padding3;
+  glm::vec3 bgColorTop;    // offset 112
+  float padding4;
+  glm::vec3 bgColorBottom; // offset 128
+  float padding5;
+};
+
+static_assert(sizeof(GPUSphere) == sizeof(PtGPUSphere), "GPUSphere layout");
+static_assert(sizeof(GPUEllipsoid) == sizeof(PtGPUEllipsoid), "GPUEllipsoid layout");
+static_assert(sizeof(GPUMaterial) == sizeof(PtGPUMaterial), "GPUMaterial layout");
+static_assert(sizeof(GPULight) == sizeof(PtGPULight), "GPULight layout");
+static_assert(sizeof(GPUVolumetricData) == sizeof(PtGPUVolumetricData), "GPUVolumetricData layout");
+static_assert(sizeof(PushConstants) == sizeof(PtPushConstants), "PushConstants layout");
+
+class HipRenderer {
+public:
+  HipRenderer() = default;
+  ~HipRenderer() { shutdown(); }
+  HipRenderer(const HipRenderer &) = delete;
+  HipRenderer &operator=(const HipRenderer &) = delete;
+
+  // Reproduce the reference shader's fixed 10 bounces regardless of maxDepth.
+  bool referenceBounceLimit = false;
+
+  // `window` is ignored.  Failure: false + message on std::cerr, like the reference.
+  bool initialize(void *window, int width, int height, int device = 0) {
+    (void)window;
+    shutdown();
+    if (pt_create(width, height, device, &handle_) != PT_OK) {
+      std::cerr << "HipRenderer initialization failed: " << pt_last_error() << std::endl;
+      handle_ = nullptr;
+      return false;
+    }
+    width_ = width;
+    height_ = height;
+    shaderPathToIndex_.clear();
+    for (int i = 0; i < pt_shader_count(); ++i) shaderPathToIndex_[pt_shader_path(i)] = i + 1;
+    return true;
+  }
+
+  void shutdown() {
+    if (handle_) pt_destroy(handle_);
+    handle_ = nullptr;
+  }
+
+  // Copies the scene; may be called every frame.  Voxels are uploaded once.
+  // Failures are reported on std::cerr and leave the previous scene in place
+  // (the reference fails silently).
+  void updateScene(const std::vector<GPUSphere> &spheres, const std::vector<GPUEllipsoid> &ellipsoids,
+                   const std::vector<GPUMaterial> &materials, const std::vector<GPULight> &lights,
+                   const std::vector<GPUVolumetricData> &volumes,
+                   const std::vector<uint8_t> &voxelData = std::vector<uint8_t>()) {
+    if (!handle_) return;
+    const int rc = pt_update_scene(
+        handle_, reinterpret_cast<const PtGPUSphere *>(spheres.data()), (int)spheres.size(),
+        reinterpret_cast<const PtGPUEllipsoid *>(ellipsoids.data()), (int)ellipsoids.size(),
+        reinterpret_cast<const PtGPUMaterial *>(materials.data()), (int)materials.size(),
+        reinterpret_cast<const PtGPULight *>(lights.data()), (int)lights.size(),
+        reinterpret_cast<const PtGPUVolumetricData *>(volumes.data()), (int)volumes.size(), voxelData.data(),
+        voxelData.size());
+    if (rc != PT_OK) std::cerr << "HipRenderer::updateScene: " << pt_last_error() << std::endl;
+  }
+
+  // Enqueues one frame and returns.
+  void render(const PushConstants &pushConstants) {
+    if (!handle_) return;
+    PushConstants pc = pushConstants;
+    if (referenceBounceLimit) pc.maxDepth = 10;
+    if (pt_render(handle_, reinterpret_cast<const PtPushConstants *>(&pc)) != PT_OK)
+      std::cerr << "HipRenderer::render: " << pt_last_error() << std::endl;
+  }
+
+  // Waits for the frames enqueued so far.
+  void present() {
+    if (handle_ && pt_present(handle_) != PT_OK) std::cerr << "HipRenderer::present: " << pt_last_error() << std::endl;
+  }
+
+  // Device pointer of the rgba8 frame (the reference returns its VkImage).
+  void *getOutputImage() const { return handle_ ? pt_device_rgba8(handle_) : nullptr; }
+
+  const std::unordered_map<std::string, int> &getShaderPathToIndexMap() const { return shaderPathToIndex_; }
+
+  // ---- beyond the reference interface ----
+  int width() const { return width_; }
+  int height() const { return height_; }
+  PtRenderer *handle() const { return handle_; }
+
+  bool readbackRGBA8(std::vector<uint8_t> &out) {
+    if (!handle_) return false;
+    out.resize((size_t)width_ * pt_local_rows(handle_) * 4);
+    return pt_readback_rgba8(handle_, out.data(), out.size()) == PT_OK;
+  }
+  bool readbackFloat(std::vector<float> &out) {
+    if (!handle_) return false;
+    out.resize((size_t)width_ * pt_local_rows(handle_) * 4);
+    return pt_readback_f32(handle_, out.data(), out.size() * sizeof(float)) == PT_OK;
+  }
+  // Binary PPM (P6) of the current frame.
+  bool writePPM(const std::string &path) {
+    std::vector<uint8_t> px;
+    if (!readbackRGBA8(px)) return false;
+    std::FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const int rows = pt_local_rows(handle_);
+    std::fprintf(f, "P6\n%d %d\n255\n", width_, rows);
+    for (size_t i = 0; i < (size_t)width_ * rows; ++i) std::fwrite(&px[4 * i], 1, 3, f);
+    std::fclose(f);
+    return true;
+  }
+
+private:
+  PtRenderer *handle_ = nullptr;
+  int width_ = 0, height_ = 0;
+  std::unordered_map<std::string, int> shaderPathToIndex_;
+};
+
+#endif

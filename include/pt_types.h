@@ -123,6 +123,7 @@ enum {
   PT_CNT_ELLIPSOID_ROOTS, /* ellipsoid tests with discriminant >= 0        */
   PT_CNT_WAVE_TRIPS,      /* device only: 4-sphere loop trips over all waves */
   PT_CNT_WAVE_SLOW_TRIPS, /* device only: trips that left the miss fast path */
+  PT_CNT_EXACT_RAYS,      /* device only: rays routed to the exact (order-preserving) sphere routine */
   PT_CNT_COUNT
 };
 

@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned int cRays = 0, cPath = 0, cLight = 0, cEmis = 0, cShaded = 0, cVoxel = 0;
   unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
   unsigned int cGroups = 0, cSlow = 0;  // wave-level: 4-sphere trips, trips that left the fast path
+  unsigned int cExact = 0;              // rays this lane sent to the exact routine
 
   for (;;) {
     // ------------------------------------------------------------------
@@ -285,9 +286,16 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       const bool finiteRay = __builtin_fabsf(rO.x) <= kBig && __builtin_fabsf(rO.y) <= kBig &&
                              __builtin_fabsf(rO.z) <= kBig && __builtin_fabsf(rD.x) <= kBig &&
                              __builtin_fabsf(rD.y) <= kBig && __builtin_fabsf(rD.z) <= kBig;
-      const bool fastLane = live && finiteRay && P.sceneHuge == 0;
+      // hitSphere assumes a unit direction.  After a few mirror bounces the
+      // shader's own rounding feedback can leave |d| far from 1; such a ray has
+      // a non-negative discriminant for most spheres, so it is cheaper to hand
+      // it to the exact routine than to let it flood the candidate queue.
+      const float dLen2 = dot3(rD, rD);
+      const bool unitDir = __builtin_fabsf(dLen2 - 1.0f) <= 2.0e-3f;
+      const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0;
       const bool special = live && !fastLane;
       if (COUNT && live) cRays++;
+      if (COUNT && special) cExact++;
       // lanes without a finite ray get one that can never produce a candidate
       const float ox = fastLane ? rO.x : 4.0e9f, oy = fastLane ? rO.y : 4.0e9f, oz = fastLane ? rO.z : 4.0e9f;
       const float dx = fastLane ? rD.x : 0.0f, dy = fastLane ? rD.y : 0.0f, dz = fastLane ? rD.z : 0.0f;
@@ -392,54 +400,88 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
       }
 
-      // Exact routine for the few rays the fast path must not take: the 64
-      // lanes each take one sphere of a chunk and the shader's sequential
-      // acceptance (including its NaN behaviour: a NaN t is accepted and then
-      // voids the upper bound for the next sphere) is reproduced chunk by chunk.
+      // Exact routine for the few rays the fast path must not (non-finite) or
+      // should not (non-unit direction) take: the 64 lanes each take one sphere
+      // of a chunk and the shader's sequential acceptance (including its NaN
+      // behaviour: a NaN t is accepted and then voids the upper bound for the
+      // next sphere) is reproduced chunk by chunk.
       unsigned long long todo = __ballot(special);
+      const unsigned long long finiteMask = (P.sceneHuge == 0) ? __ballot(finiteRay) : 0ull;
       while (todo != 0ull) {
         const int owner = (int)__builtin_ctzll(todo);
         todo &= todo - 1ull;
         const float eox = __shfl(rO.x, owner), eoy = __shfl(rO.y, owner), eoz = __shfl(rO.z, owner);
         const float edx = __shfl(rD.x, owner), edy = __shfl(rD.y, owner), edz = __shfl(rD.z, owner);
-        float C = __shfl(rTmax, owner); // closestT
+        const float etmax = __shfl(rTmax, owner);
+        float C = etmax; // closestT
         int win = -1;
         unsigned int roots = 0;
-        for (int base = 0; base < Ns; base += 64) {
-          const int j = base + lane;
-          const bool inb = j < Ns;
-          const float4 sp = P.spheres[inb ? j : 0];
-          const float ocx = eox - sp.x, ocy = eoy - sp.y, ocz = eoz - sp.z;
-          const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
-          const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
-          const float cc = __builtin_fmaf(-sp.w, sp.w, dd);
-          const float disc = __builtin_fmaf(hb, hb, -cc);
-          const bool root = inb && !(disc < 0.0f);
-          const float sq = __builtin_sqrtf(disc);
+#define PT_EXACT_SPHERE(J, INB)                                                   \
+          /* one sphere per lane: coalesced 16-byte loads from the plain array  \
+             (the LDS pair image would be read with a 4-way bank conflict) */     \
+          const float4 sp = P.spheres[(INB) ? (J) : 0];                           \
+          const float ocx = eox - sp.x, ocy = eoy - sp.y, ocz = eoz - sp.z;       \
+          const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx)); \
+          const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)); \
+          const float cc = __builtin_fmaf(-sp.w, sp.w, dd);                       \
+          const float disc = __builtin_fmaf(hb, hb, -cc);                         \
+          const bool root = (INB) && !(disc < 0.0f);                              \
+          const float sq = __builtin_sqrtf(disc);                                 \
           const float t0 = -hb - sq, t1 = -hb + sq;
-          // a NaN root passes both range tests of hitSphere whatever closestT is
-          const bool nanacc = root && ((t0 != t0) || ((t0 < tMin) && (t1 != t1)));
-          float v = t0;
-          bool valid = root && !nanacc;
-          if (t0 < tMin) { v = t1; valid = valid && !(t1 < tMin); }
-          if (COUNT) roots += (unsigned int)__popcll(__ballot(root));
-          const unsigned long long nm = __ballot(nanacc);
-          if (nm != 0ull) {
-            const int kl = 63 - (int)__builtin_clzll(nm);
-            C = __builtin_nanf("");
-            win = base + kl;
-            valid = valid && lane > kl;
+        if ((finiteMask >> owner) & 1ull) {
+          // Finite ray, finite scene: no NaN can appear, the result is the
+          // smallest root >= tMin (later sphere on a tie) if it is <= tMax.
+          // Each lane keeps the best of its own spheres; one reduction at the end.
+          float myBest = __builtin_inff();
+          int myIdx = -1;
+          for (int base = 0; base < Ns; base += 64) {
+            const int j = base + lane;
+            const bool inb = j < Ns;
+            PT_EXACT_SPHERE(j, inb)
+            const float v = (t0 < tMin) ? t1 : t0;
+            if (root && !(v < tMin) && v <= myBest) { myBest = v; myIdx = j; }
+            if (COUNT) roots += root ? 1u : 0u;
           }
-          // accepted iff !(v > closestT); with closestT = NaN every valid root is
-          const bool cand = valid && !(v > C);
-          if (__ballot(cand) != 0ull) {
-            float mn = cand ? v : __builtin_inff();
-            for (int off = 32; off > 0; off >>= 1) mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
-            const unsigned long long em = __ballot(cand && v == mn);
-            C = mn;
-            win = base + 63 - (int)__builtin_clzll(em);
+          unsigned long long key = ((unsigned long long)__float_as_uint(myBest) << 32) |
+                                   (unsigned long long)(~((unsigned int)myIdx + 1u));
+          for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long other = __shfl_xor(key, off, 64);
+            key = other < key ? other : key;
+          }
+          const float mn = __uint_as_float((unsigned int)(key >> 32));
+          const unsigned int widx = ~(unsigned int)key - 1u;
+          if (widx < (unsigned int)Ns && !(mn > C)) { C = mn; win = (int)widx; }
+          if (COUNT) for (int off = 32; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
+        } else {
+          for (int base = 0; base < Ns; base += 64) {
+            const int j = base + lane;
+            const bool inb = j < Ns;
+            PT_EXACT_SPHERE(j, inb)
+            // a NaN root passes both range tests of hitSphere whatever closestT is
+            const bool nanacc = root && ((t0 != t0) || ((t0 < tMin) && (t1 != t1)));
+            float v = t0;
+            bool valid = root && !nanacc;
+            if (t0 < tMin) { v = t1; valid = valid && !(t1 < tMin); }
+            if (COUNT) roots += (unsigned int)__popcll(__ballot(root));
+            const unsigned long long nm = __ballot(nanacc);
+            if (nm != 0ull) {
+              const int kl = 63 - (int)__builtin_clzll(nm);
+              C = __builtin_nanf("");
+              win = base + kl;
+              valid = valid && lane > kl;
+            }
+            // accepted iff !(v > closestT); with closestT = NaN every valid root is
+            const bool cand = valid && !(v > C);
+            if (__ballot(cand) != 0ull) {
+              float mn = cand ? v : __builtin_inff();
+              for (int off = 32; off > 0; off >>= 1) mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
+              const unsigned long long em = __ballot(cand && v == mn);
+              C = mn;
+              win = base + 63 - (int)__builtin_clzll(em);
+            }
           }
         }
+#undef PT_EXACT_SPHERE
         if (lane == owner) {
           bestT = C;
           bestIdx = win;
@@ -823,15 +865,16 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 
   if (COUNT) {
     // wave reduction, then one atomic per counter per wave
-    unsigned long long v[12];
+    unsigned long long v[13];
     v[0] = cRays; v[1] = cPath; v[2] = cLight; v[3] = cEmis;
     v[4] = (unsigned long long)cRays * (unsigned long long)(Ns > 0 ? Ns : 0);
     v[5] = (unsigned long long)cRays * (unsigned long long)(Ne > 0 ? Ne : 0);
     v[6] = cVoxel; v[7] = cShaded; v[8] = cRoots; v[9] = cERoots;
     // wave-level counts: every live lane of a wave saw the same trips, so take lane-max, not the sum
-    v[10] = 0; v[11] = 0;
+    v[10] = 0; v[11] = 0; v[12] = cExact;
 #pragma unroll
-    for (int c = 0; c < 10; ++c) {
+    for (int c = 0; c < 13; ++c) {
+      if (c == 10 || c == 11) continue;
       unsigned long long x = v[c];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0) atomicAdd(&P.counters[c], x);

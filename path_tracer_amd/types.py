@@ -90,6 +90,7 @@ COUNTER_NAMES = (
     "ellipsoid_roots",
     "wave_trips",       # device only
     "wave_slow_trips",  # device only
+    "exact_rays",       # device only
 )
 N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 
