@@ -88,7 +88,8 @@ struct PtRenderer {
   bool sceneHuge = false; // a sphere with a non-finite or > 1e9 centre/radius: rays take the exact routine
   int numSpheres = 0, numEllipsoids = 0, numMaterials = 0, numLights = 0, numVolumes = 0;
   int numEmSpheres = 0, numEmEllipsoids = 0;
-  DevBuf dSpheres, dSpherePairs, dSphereMat, dEllipsoids, dEllipsoidMat, dMaterials, dLights, dEmSpheres, dEmEllipsoids, dVoxels;
+  DevBuf dSpheres, dImage, dVoxels;
+  int imageFloat4s = 0, offEll = 0, offMat = 0, offLight = 0, offEmS = 0, offEmE = 0, offMatIdx = 0, matIdxEllBase = 0;
   bool voxelsUploaded = false;
   size_t voxelBytes = 0;
   PtGPUVolumetricData volume0{};
@@ -185,14 +186,15 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
     P.volMaterial = v.materialIndex;
   }
   P.spheres = (const float4 *)r->dSpheres.p;
-  P.spherePairs = (const float4 *)r->dSpherePairs.p;
-  P.sphereMat = (const int *)r->dSphereMat.p;
-  P.ellipsoids = (const float4 *)r->dEllipsoids.p;
-  P.ellipsoidMat = (const int *)r->dEllipsoidMat.p;
-  P.materials = (const float4 *)r->dMaterials.p;
-  P.lights = (const float4 *)r->dLights.p;
-  P.emSpheres = (const int *)r->dEmSpheres.p;
-  P.emEllipsoids = (const int *)r->dEmEllipsoids.p;
+  P.image = (const float4 *)r->dImage.p;
+  P.imageFloat4s = r->imageFloat4s;
+  P.offEll = r->offEll;
+  P.offMat = r->offMat;
+  P.offLight = r->offLight;
+  P.offEmS = r->offEmS;
+  P.offEmE = r->offEmE;
+  P.offMatIdx = r->offMatIdx;
+  P.matIdxEllBase = r->matIdxEllBase;
   P.voxels = (const uint8_t *)r->dVoxels.p;
   P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8.p);
   P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr));
@@ -205,7 +207,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
   // staged in LDS when they fit (<= 80 KiB: two 512-thread groups per CU;
   // <= 160 KiB: one 1024-thread group); otherwise read from global memory.
   // LDS per workgroup: the object image (if staged) + 1 KiB of queue/result scratch per wave.
-  size_t objBytes = (4 * (size_t)((P.numSpheres + 3) / 4) + 4 * (size_t)P.numEllipsoids) * sizeof(float4);
+  size_t objBytes = (size_t)r->imageFloat4s * sizeof(float4);
   bool useLds = objBytes + 16 * 1024 <= 160 * 1024;
   if (r->objectSource == 1 && !useLds)
     return fail(PT_ERR_INVALID, "pt_render: scene does not fit the 160 KiB LDS (PT_OPT_OBJECT_SOURCE=1)");
@@ -294,8 +296,7 @@ void pt_destroy(PtRenderer *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dSpherePairs, &r->dSphereMat, &r->dEllipsoids, &r->dEllipsoidMat, &r->dMaterials, &r->dLights,
-                    &r->dEmSpheres, &r->dEmEllipsoids, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch};
+  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch};
   for (DevBuf *b : bufs) b->release();
   if (r->evBegin) (void)hipEventDestroy(r->evBegin);
   if (r->evEnd) (void)hipEventDestroy(r->evEnd);
@@ -334,64 +335,89 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   // The previous frame may still be reading the buffers we are about to refill.
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
 
-  // AoS records -> SoA device arrays.
+  // AoS records -> one scene image (see FrameParams in pt_device.hpp) + the plain sphere array.
+  if (num_materials > 65536) return fail(PT_ERR_INVALID, "pt_update_scene: more than 65536 materials");
   // Spheres: the reference repacks to {center, radius, materialIndex}
   // (reference src/VulkanRenderer.cpp:803-822); colour is dropped.
   std::vector<float4> hs((size_t)num_spheres);
-  std::vector<int> hsm((size_t)num_spheres);
-  std::vector<int> emS;
   bool sceneHuge = false;
   for (int i = 0; i < num_spheres; ++i) {
     hs[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
-    hsm[i] = spheres[i].materialIndex;
     for (float v : {hs[i].x, hs[i].y, hs[i].z, hs[i].w})
       if (!(std::fabs(v) <= 1.0e9f)) sceneHuge = true;
-    if (materials[hsm[i]].transparencyEmissive[1] > 0.0f) emS.push_back(i);
   }
+  std::vector<float4> img;
   // The intersection loop reads spheres two at a time:
   //   (cx0, cx1, cy0, cy1) (cz0, cz1, r0, r1)
   // padded with copies of the last sphere to whole groups of four (the copies
   // can never win: their index is >= the sphere count).
   const int nGroups = (num_spheres + 3) / 4;
-  std::vector<float4> hp((size_t)nGroups * 4);
   for (int p = 0; p < nGroups * 2; ++p) {
     const float4 &s0 = hs[std::min(2 * p, num_spheres - 1)];
     const float4 &s1 = hs[std::min(2 * p + 1, num_spheres - 1)];
-    hp[2 * p] = make_float4(s0.x, s1.x, s0.y, s1.y);
-    hp[2 * p + 1] = make_float4(s0.z, s1.z, s0.w, s1.w);
+    img.push_back(make_float4(s0.x, s1.x, s0.y, s1.y));
+    img.push_back(make_float4(s0.z, s1.z, s0.w, s1.w));
   }
   // Ellipsoids: centre + qw, 1/radii + max radius, -q.xyz, -2 q.xyz.  1/radii is
   // the same IEEE division hitEllipsoid does per test (reference
   // shaders/raytrace.comp:178); negation and doubling are exact.
-  std::vector<float4> he((size_t)num_ellipsoids * 4);
-  std::vector<int> hem((size_t)num_ellipsoids);
-  std::vector<int> emE;
+  const int offEll = (int)img.size();
   for (int i = 0; i < num_ellipsoids; ++i) {
     const PtGPUEllipsoid &e = ellipsoids[i];
     float maxR = std::max(std::max(e.radii[0], e.radii[1]), e.radii[2]); // raytrace.comp:467
-    he[4 * i + 0] = make_float4(e.center[0], e.center[1], e.center[2], e.rotation[3]);
-    he[4 * i + 1] = make_float4(1.0f / e.radii[0], 1.0f / e.radii[1], 1.0f / e.radii[2], maxR);
-    he[4 * i + 2] = make_float4(-e.rotation[0], -e.rotation[1], -e.rotation[2], 0.0f);
-    he[4 * i + 3] = make_float4(-2.0f * e.rotation[0], -2.0f * e.rotation[1], -2.0f * e.rotation[2], 0.0f);
-    hem[i] = e.materialIndex;
-    if (materials[hem[i]].transparencyEmissive[1] > 0.0f) emE.push_back(i);
+    img.push_back(make_float4(e.center[0], e.center[1], e.center[2], e.rotation[3]));
+    img.push_back(make_float4(1.0f / e.radii[0], 1.0f / e.radii[1], 1.0f / e.radii[2], maxR));
+    img.push_back(make_float4(-e.rotation[0], -e.rotation[1], -e.rotation[2], 0.0f));
+    img.push_back(make_float4(-2.0f * e.rotation[0], -2.0f * e.rotation[1], -2.0f * e.rotation[2], 0.0f));
+  }
+  const int offMat = (int)img.size();
+  for (int i = 0; i < num_materials; ++i) {
+    const float *f = materials[i].colorAndAmbient;
+    for (int k = 0; k < 5; ++k) img.push_back(make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]));
   }
   // Lights: vec4(position, intensity) (reference src/VulkanRenderer.cpp:876-883).
-  std::vector<float4> hl((size_t)num_lights);
+  const int offLight = (int)img.size();
   for (int i = 0; i < num_lights; ++i)
-    hl[i] = make_float4(lights[i].position[0], lights[i].position[1], lights[i].position[2], lights[i].intensity);
-  std::vector<PtGPUMaterial> hm(materials, materials + num_materials);
+    img.push_back(make_float4(lights[i].position[0], lights[i].position[1], lights[i].position[2], lights[i].intensity));
+  // Emissive objects, in object order: what calculateLighting's scan over all
+  // objects and their materials finds (reference shaders/raytrace.comp:367-480).
+  auto bits = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
+  const int offEmS = (int)img.size();
+  int nEmS = 0;
+  for (int i = 0; i < num_spheres; ++i) {
+    const PtGPUMaterial &m = materials[spheres[i].materialIndex];
+    if (!(m.transparencyEmissive[1] > 0.0f)) continue;
+    img.push_back(hs[i]);
+    img.push_back(make_float4(m.colorAndAmbient[0], m.colorAndAmbient[1], m.colorAndAmbient[2], m.transparencyEmissive[1]));
+    img.push_back(make_float4(bits((int)m.transparencyEmissive[2]), bits(i), 0.0f, 0.0f));
+    ++nEmS;
+  }
+  const int offEmE = (int)img.size();
+  int nEmE = 0;
+  for (int i = 0; i < num_ellipsoids; ++i) {
+    const PtGPUEllipsoid &e = ellipsoids[i];
+    const PtGPUMaterial &m = materials[e.materialIndex];
+    if (!(m.transparencyEmissive[1] > 0.0f)) continue;
+    float maxR = std::max(std::max(e.radii[0], e.radii[1]), e.radii[2]);
+    img.push_back(make_float4(e.center[0], e.center[1], e.center[2], maxR));
+    img.push_back(make_float4(m.colorAndAmbient[0], m.colorAndAmbient[1], m.colorAndAmbient[2], m.transparencyEmissive[1]));
+    img.push_back(make_float4(bits(i), 0.0f, 0.0f, 0.0f));
+    ++nEmE;
+  }
+  // uint16 material index per sphere, then per ellipsoid
+  const int offMatIdx = (int)img.size();
+  {
+    std::vector<uint16_t> mi((size_t)num_spheres + num_ellipsoids);
+    for (int i = 0; i < num_spheres; ++i) mi[i] = (uint16_t)spheres[i].materialIndex;
+    for (int i = 0; i < num_ellipsoids; ++i) mi[num_spheres + i] = (uint16_t)ellipsoids[i].materialIndex;
+    const size_t n4 = (mi.size() * 2 + 15) / 16;
+    img.resize(img.size() + n4, make_float4(0, 0, 0, 0));
+    if (!mi.empty()) std::memcpy(&img[offMatIdx], mi.data(), mi.size() * 2);
+  }
 
   int rc;
   if ((rc = upload(r->dSpheres, hs, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dSpherePairs, hp, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dSphereMat, hsm, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dEllipsoids, he, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dEllipsoidMat, hem, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dMaterials, hm, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dLights, hl, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dEmSpheres, emS, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dEmEllipsoids, emE, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dImage, img, r->stream)) != PT_OK) return rc;
 
   if (num_volumes > 0) {
     r->volume0 = volumes[0];
@@ -420,8 +446,16 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   r->numMaterials = num_materials;
   r->numLights = num_lights;
   r->numVolumes = num_volumes;
-  r->numEmSpheres = (int)emS.size();
-  r->numEmEllipsoids = (int)emE.size();
+  r->numEmSpheres = nEmS;
+  r->numEmEllipsoids = nEmE;
+  r->imageFloat4s = (int)img.size();
+  r->offEll = offEll;
+  r->offMat = offMat;
+  r->offLight = offLight;
+  r->offEmS = offEmS;
+  r->offEmE = offEmE;
+  r->offMatIdx = offMatIdx;
+  r->matIdxEllBase = num_spheres;
   r->sceneValid = true;
   return PT_OK;
 }

@@ -30,7 +30,7 @@ namespace ptdev {
 
 constexpr float kMaxDistance = 1e10f; // raytrace.comp:94
 constexpr float kEpsilon = 0.001f;    // raytrace.comp:95
-constexpr int kTileDim = 16;          // pixels per tile edge (4 sub-tiles of 8x8)
+constexpr int kTileDim = 8;           // pixels per tile edge: one 8x8 tile = one refill of a whole wave
 constexpr int kTilePixels = kTileDim * kTileDim;
 
 struct FrameParams {
@@ -52,17 +52,22 @@ struct FrameParams {
   float volPos[3], v0[3], v1[3], boxMin[3], boxMax[3], extent[3];
   int res[3];
   int volMaterial;
-  // scene, SoA
-  const float4 *spheres;    // (cx, cy, cz, r), one per sphere
-  const float4 *spherePairs; // 2 float4 per pair of spheres: (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1),
-                             // padded with copies of the last sphere to a multiple of 4 spheres
-  const int *sphereMat;
-  const float4 *ellipsoids; // 4 per ellipsoid: (c, qw) (1/radii, maxRadius) (-q.xyz, 0) (-2q.xyz, 0)
-  const int *ellipsoidMat;
-  const float4 *materials;  // 5 per material, as GPUMaterial
-  const float4 *lights;     // (pos, intensity)
-  const int *emSpheres;     // indices of spheres whose material has emissiveStrength > 0, ascending
-  const int *emEllipsoids;
+  // Scene image: one contiguous block of float4, copied into LDS by every
+  // workgroup when it fits (offsets in float4 units):
+  //   [0)          sphere pairs, 2 float4 per pair (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1),
+  //                padded with copies of the last sphere to a multiple of 4 spheres
+  //   [offEll)     4 per ellipsoid: (c,qw) (1/radii,maxRadius) (-q.xyz,0) (-2q.xyz,0)
+  //   [offMat)     5 per material, as GPUMaterial
+  //   [offLight)   1 per light: (pos, intensity)
+  //   [offEmS)     3 per emissive sphere, ascending sphere index:
+  //                (c,r) (material colour, emissiveStrength) (shaderIndex, sphereIndex as int bits)
+  //   [offEmE)     3 per emissive ellipsoid: (c,maxRadius) (material colour, emissiveStrength) (ellipsoidIndex bits)
+  //   [offMatIdx)  uint16 material index per sphere, then per ellipsoid
+  const float4 *image;
+  int imageFloat4s;
+  int offEll, offMat, offLight, offEmS, offEmE, offMatIdx;
+  int matIdxEllBase;         // element offset of the ellipsoid part of the uint16 table
+  const float4 *spheres;     // (cx, cy, cz, r), one per sphere, global memory
   const uint8_t *voxels;
   uint32_t *outRgba8;
   float4 *outF32;           // may be null
@@ -161,26 +166,29 @@ enum : int {
 
 template <bool COUNT, bool LDS_OBJECTS>
 __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
-  // LDS image: sphere pairs (2 float4 per pair: (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1)),
-  // padded to whole groups of 4 spheres, then 4 float4 per ellipsoid.
   extern __shared__ float4 s_obj[];
   const int Ns = P.numSpheres, Ne = P.numEllipsoids;
-  const int nGroups = (Ns + 3) >> 2;  // groups of 4 spheres = 4 float4
-  const int ellBase = 4 * nGroups;
+  const int nGroups = (Ns + 3) >> 2; // trips of the sphere loop: 4 spheres = 4 float4
   if (LDS_OBJECTS) {
-    for (int i = threadIdx.x; i < 4 * nGroups; i += blockDim.x) s_obj[i] = P.spherePairs[i];
-    for (int i = threadIdx.x; i < 4 * Ne; i += blockDim.x) s_obj[ellBase + i] = P.ellipsoids[i];
+    for (int i = threadIdx.x; i < P.imageFloat4s; i += blockDim.x) s_obj[i] = P.image[i];
     __syncthreads();
   }
-  const float4 *__restrict__ g_pairs = P.spherePairs;
-  const float4 *__restrict__ g_ell = P.ellipsoids;
-#define PT_PAIR(i) (LDS_OBJECTS ? s_obj[(i)] : g_pairs[(i)])
-#define PT_ELL(j, k) (LDS_OBJECTS ? s_obj[ellBase + 4 * (j) + (k)] : g_ell[4 * (j) + (k)])
+  const float4 *__restrict__ g_img = P.image;
+#define PT_IMG(i) (LDS_OBJECTS ? s_obj[(i)] : g_img[(i)])
+#define PT_PAIR(i) PT_IMG(i)
+#define PT_ELL(j, k) PT_IMG(P.offEll + 4 * (j) + (k))
+#define PT_MAT(m, k) PT_IMG(P.offMat + 5 * (m) + (k))
+#define PT_LIGHT(i) PT_IMG(P.offLight + (i))
+#define PT_EMS(e, k) PT_IMG(P.offEmS + 3 * (e) + (k))
+#define PT_EME(e, k) PT_IMG(P.offEmE + 3 * (e) + (k))
+#define PT_MATIDX(i)                                                                        \
+  ((int)(LDS_OBJECTS ? ((const unsigned short *)(s_obj + P.offMatIdx))[(i)]                 \
+                     : ((const unsigned short *)(g_img + P.offMatIdx))[(i)]))
 
   const int lane = threadIdx.x & 63;
   const unsigned long long laneMaskLt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   // per-wave scratch behind the object image: 128-entry candidate ring + 64 result slots (1 KiB)
-  const int objFloat4s = LDS_OBJECTS ? (4 * nGroups + 4 * Ne) : 0;
+  const int objFloat4s = LDS_OBJECTS ? P.imageFloat4s : 0;
   float4 *const w_area = s_obj + objFloat4s + 64 * (int)(threadIdx.x >> 6);
   unsigned int *const w_queue = (unsigned int *)w_area;
   unsigned long long *const w_slot = (unsigned long long *)(w_area + 32);
@@ -210,6 +218,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
   unsigned int cGroups = 0, cSlow = 0;  // wave-level: 4-sphere trips, trips that left the fast path
   unsigned int cExact = 0;              // rays this lane sent to the exact routine
+  unsigned long long cycRefill = 0, cycSpheres = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
+#define PT_PHASE(ACC) if (COUNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
+  if (COUNT) tPhase = __builtin_amdgcn_s_memtime();
 
   for (;;) {
     // ------------------------------------------------------------------
@@ -260,6 +271,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       idleMask = __ballot(state == ST_IDLE);
     }
     if (__ballot(state != ST_IDLE) == 0ull) break;
+    PT_PHASE(cycRefill)
 
     // ------------------------------------------------------------------
     // 2. traceRay for every live lane (raytrace.comp:212-241); bestIdx < Ns is
@@ -322,7 +334,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float eox = __shfl(ox, owner), eoy = __shfl(oy, owner), eoz = __shfl(oz, owner);
         const float edx = __shfl(dx, owner), edy = __shfl(dy, owner), edz = __shfl(dz, owner);
         float cx, cy, cz, rr;
-        if (LDS_OBJECTS) {
+        if (LDS_OBJECTS) { // the pair image starts at float4 0 of the scene image
           const float *sf = (const float *)s_obj;
           const int f = 8 * (idx >> 1) + (idx & 1);
           cx = sf[f]; cy = sf[f + 2]; cz = sf[f + 4]; rr = sf[f + 6];
@@ -490,6 +502,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       }
     }
 
+    PT_PHASE(cycSpheres)
     // hitEllipsoid (raytrace.comp:171-210), after the spheres as in traceRay
     if (live) {
       const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
@@ -521,6 +534,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       }
     }
 
+    PT_PHASE(cycEll)
     // ------------------------------------------------------------------
     // 3. each live lane consumes its result and runs until it has emitted
     //    its next ray or finished its pixel
@@ -536,8 +550,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       } else if (state == ST_LIGHT) {
         if (!hitAny) {
           // raytrace.comp:348-363
-          const float4 L = P.lights[k];
-          const float4 m0 = P.materials[5 * hitMat], m1 = P.materials[5 * hitMat + 1];
+          const float4 L = PT_LIGHT(k);
+          const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
           const V3 surfaceColor = xyz(m0);
           const V3 lightVec = sub3(xyz(L), hitP);
           const float distance = length3(lightVec);
@@ -555,8 +569,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       } else if (state == ST_TOON_LIGHT) {
         if (!hitAny) {
           // toon.glsl:22-39
-          const float4 L = P.lights[k];
-          const float4 m0 = P.materials[5 * hitMat], m1 = P.materials[5 * hitMat + 1];
+          const float4 L = PT_LIGHT(k);
+          const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
           const V3 surfaceColor = xyz(m0);
           const V3 lightVec = sub3(xyz(L), hitP);
           const float distance = length3(lightVec);
@@ -603,7 +617,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             if (tFar >= tNear && tFar > 0.0f) {
               tNear = glmax(tNear, 0.0f);
               tFar = glmin(tFar, maxDist);
-              const float4 m4 = P.materials[5 * P.volMaterial + 4];
+              const float4 m4 = PT_MAT(P.volMaterial, 4);
               const float absorptionCoeff = m4.w;
               const float rxf = (float)P.res[0], ryf = (float)P.res[1], rzf = (float)P.res[2];
               const int rx = P.res[0], ry = P.res[1], rz = P.res[2];
@@ -663,7 +677,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           if (bestIdx < Ns) { // hitSphere :161-165
             const float4 s = P.spheres[bestIdx];
             hitN = scale3(sub3(hitP, xyz(s)), 1.0f / s.w);
-            hitMat = P.sphereMat[bestIdx];
+            hitMat = PT_MATIDX(bestIdx);
           } else { // hitEllipsoid :198-207
             const int j = bestIdx - Ns;
             const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
@@ -674,10 +688,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const V3 localPoint = madd3(oc, bestT, dir);
             const V3 normalLocal = mul3(mul3(localPoint, invR), invR);
             hitN = normalize3(rotate_q(normalLocal, neg3(nq), neg3(nq2), e0.w));
-            hitMat = P.ellipsoidMat[j];
+            hitMat = PT_MATIDX(P.matIdxEllBase + j);
           }
-          const float4 m0 = P.materials[5 * hitMat];
-          const float4 m2 = P.materials[5 * hitMat + 2];
+          const float4 m0 = PT_MAT(hitMat, 0);
+          const float4 m2 = PT_MAT(hitMat, 2);
           const V3 surfaceColor = xyz(m0);
           const float emissiveStrength = m2.y;
           if (emissiveStrength > 0.0f) // :637-639
@@ -709,7 +723,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         case GO_NEXT_LIGHT:
         case GO_NEXT_TOON_LIGHT: {
           if (k < P.numLights) { // getShadowFactor (:243-253)
-            const float4 L = P.lights[k];
+            const float4 L = PT_LIGHT(k);
             const V3 lightVec = sub3(xyz(L), hitP);
             const float distToLight = length3(lightVec);
             rO = hitP;
@@ -722,8 +736,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             k = 0;
             step = GO_NEXT_EM_SPHERE;
           } else { // toon.glsl:42-47: result.color + result.emissive
-            const float4 m0 = P.materials[5 * hitMat];
-            const float4 m2 = P.materials[5 * hitMat + 2];
+            const float4 m0 = PT_MAT(hitMat, 0);
+            const float4 m2 = PT_MAT(hitMat, 2);
             V3 em = mk3(0, 0, 0);
             if (m2.y > 0.0f) em = scale3(xyz(m0), m2.y);
             lit = add3(lit, em);
@@ -734,18 +748,15 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         case GO_NEXT_EM_SPHERE: { // raytrace.comp:367-443, over the precomputed emissive list
           step = GO_NEXT_EM_ELLIPSOID;
           while (k < P.numEmSpheres) {
-            const int si = P.emSpheres[k];
+            const float4 s = PT_EMS(k, 0), sm = PT_EMS(k, 1), sx = PT_EMS(k, 2);
+            const int si = __float_as_int(sx.y);
             if (si >= Ns) { k = P.numEmSpheres; break; }
-            const float4 s = P.spheres[si];
-            const int mi = P.sphereMat[si];
-            const float4 sm0 = P.materials[5 * mi];
-            const float4 sm2 = P.materials[5 * mi + 2];
-            float sphereEmissive = sm2.y;
-            V3 emissiveColor = xyz(sm0);
+            float sphereEmissive = sm.w;
+            V3 emissiveColor = xyz(sm);
             const V3 toSphere = sub3(xyz(s), hitP);
             const float distToSphere = length3(toSphere);
             const V3 dirToSphere = div3s(toSphere, distToSphere);
-            const int sphereShaderIndex = (int)sm2.z;
+            const int sphereShaderIndex = __float_as_int(sx.x);
             bool skip = false;
             if (sphereShaderIndex != 0) { // :377-414
               const V3 approximateHitPoint = sub3(xyz(s), scale3(dirToSphere, s.w));
@@ -755,7 +766,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                 // toon keeps result.emissive = surfaceColor * emissiveStrength (toon.glsl:45-47);
                 // its light loop only feeds result.color, which this caller drops, so the
                 // shadow rays it would issue are elided (but still counted as issued)
-                emissiveColor = scale3(xyz(sm0), sphereEmissive);
+                emissiveColor = scale3(xyz(sm), sphereEmissive);
                 if (COUNT) { cLight += (unsigned int)P.numLights; cRays += (unsigned int)P.numLights; }
               } else {
                 emissiveColor = mk3(0, 0, 0);
@@ -785,12 +796,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         case GO_NEXT_EM_ELLIPSOID: { // raytrace.comp:445-480
           step = GO_AFTER_LIGHTING;
           while (k < P.numEmEllipsoids) {
-            const int ei = P.emEllipsoids[k];
+            const float4 e0 = PT_EME(k, 0), em = PT_EME(k, 1), ex = PT_EME(k, 2);
+            const int ei = __float_as_int(ex.x);
             if (ei >= Ne) { k = P.numEmEllipsoids; break; }
-            const float4 e0 = PT_ELL(ei, 0), e1 = PT_ELL(ei, 1);
-            const int mi = P.ellipsoidMat[ei];
-            const float4 em0 = P.materials[5 * mi];
-            const float4 em2 = P.materials[5 * mi + 2];
             const V3 toE = sub3(xyz(e0), hitP);
             const float distE = length3(toE);
             const V3 dirE = div3s(toE, distE);
@@ -798,9 +806,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             if (alignment > 0.0f) {
               rO = madd3(hitP, kEpsilon, hitN);
               rD = dirE;
-                rTmax = (distE - e1.w) - kEpsilon;
-              const float attenuation = em2.y / ((1.0f + 0.5f * distE) + (0.1f * distE) * distE);
-              pending = scale3(scale3(xyz(em0), alignment), attenuation);
+                rTmax = (distE - e0.w) - kEpsilon;
+              const float attenuation = em.w / ((1.0f + 0.5f * distE) + (0.1f * distE) * distE);
+              pending = scale3(scale3(xyz(em), alignment), attenuation);
               state = ST_EM_ELLIPSOID;
               if (COUNT) cEmis++;
               step = GO_EMITTED;
@@ -811,8 +819,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           break;
         }
         case GO_AFTER_LIGHTING: { // raytrace.comp:645-671
-          const float4 m1 = P.materials[5 * hitMat + 1];
-          const float4 m2 = P.materials[5 * hitMat + 2];
+          const float4 m1 = PT_MAT(hitMat, 1);
+          const float4 m2 = PT_MAT(hitMat, 2);
           const float transparency = m2.x;
           const float reflectivity = m1.w;
           bool cont = false;
@@ -861,9 +869,17 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
       }
     }
+    PT_PHASE(cycShade)
   }
+#undef PT_PHASE
 
   if (COUNT) {
+    if (lane == 0) {
+      atomicAdd(&P.counters[13], cycRefill);
+      atomicAdd(&P.counters[14], cycSpheres);
+      atomicAdd(&P.counters[15], cycEll);
+      atomicAdd(&P.counters[16], cycShade);
+    }
     // wave reduction, then one atomic per counter per wave
     unsigned long long v[13];
     v[0] = cRays; v[1] = cPath; v[2] = cLight; v[3] = cEmis;
@@ -889,8 +905,14 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       if (lane == 0) { atomicAdd(&P.counters[10], (unsigned long long)g); atomicAdd(&P.counters[11], (unsigned long long)sl); }
     }
   }
+#undef PT_IMG
 #undef PT_PAIR
 #undef PT_ELL
+#undef PT_MAT
+#undef PT_LIGHT
+#undef PT_EMS
+#undef PT_EME
+#undef PT_MATIDX
 #undef PT_PAIR_DISC
 #undef PT_ENQUEUE
 }

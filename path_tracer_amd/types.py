@@ -91,6 +91,10 @@ COUNTER_NAMES = (
     "wave_trips",       # device only
     "wave_slow_trips",  # device only
     "exact_rays",       # device only
+    "cyc_refill",       # device only, wave-cycles
+    "cyc_spheres",
+    "cyc_ellipsoids",
+    "cyc_shade",
 )
 N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 
