@@ -121,13 +121,14 @@ enum {
   PT_CNT_SHADED_HITS,     /* calculateLighting calls                      */
   PT_CNT_SPHERE_ROOTS,    /* sphere tests with discriminant >= 0 (sqrt taken) */
   PT_CNT_ELLIPSOID_ROOTS, /* ellipsoid tests with discriminant >= 0        */
-  PT_CNT_WAVE_TRIPS,      /* device only: 4-sphere loop trips over all waves */
+  PT_CNT_WAVE_TRIPS,      /* device only: 8-sphere loop trips over all waves */
   PT_CNT_WAVE_SLOW_TRIPS, /* device only: trips that left the miss fast path */
   PT_CNT_EXACT_RAYS,      /* device only: rays routed to the exact (order-preserving) sphere routine */
   PT_CNT_CYC_REFILL,      /* device only: wave-cycles (s_memtime) spent assigning pixels      */
-  PT_CNT_CYC_SPHERES,     /* device only: wave-cycles in the sphere loop, queue and exact routine */
+  PT_CNT_CYC_SPHERES,     /* device only: wave-cycles in the sphere loop and candidate queue    */
   PT_CNT_CYC_ELLIPSOIDS,  /* device only: wave-cycles in the ellipsoid loop                   */
   PT_CNT_CYC_SHADE,       /* device only: wave-cycles consuming results / shading / marching  */
+  PT_CNT_CYC_EXACT,       /* device only: wave-cycles in the exact sphere routine             */
   PT_CNT_COUNT
 };
 

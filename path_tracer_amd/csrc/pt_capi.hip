@@ -349,10 +349,10 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   std::vector<float4> img;
   // The intersection loop reads spheres two at a time:
   //   (cx0, cx1, cy0, cy1) (cz0, cz1, r0, r1)
-  // padded with copies of the last sphere to whole groups of four (the copies
+  // padded with copies of the last sphere to whole groups of eight (the copies
   // can never win: their index is >= the sphere count).
-  const int nGroups = (num_spheres + 3) / 4;
-  for (int p = 0; p < nGroups * 2; ++p) {
+  const int nGroups = (num_spheres + 7) / 8;
+  for (int p = 0; p < nGroups * 4; ++p) {
     const float4 &s0 = hs[std::min(2 * p, num_spheres - 1)];
     const float4 &s1 = hs[std::min(2 * p + 1, num_spheres - 1)];
     img.push_back(make_float4(s0.x, s1.x, s0.y, s1.y));

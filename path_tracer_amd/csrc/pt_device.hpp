@@ -55,7 +55,7 @@ struct FrameParams {
   // Scene image: one contiguous block of float4, copied into LDS by every
   // workgroup when it fits (offsets in float4 units):
   //   [0)          sphere pairs, 2 float4 per pair (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1),
-  //                padded with copies of the last sphere to a multiple of 4 spheres
+  //                padded with copies of the last sphere to a multiple of 8 spheres
   //   [offEll)     4 per ellipsoid: (c,qw) (1/radii,maxRadius) (-q.xyz,0) (-2q.xyz,0)
   //   [offMat)     5 per material, as GPUMaterial
   //   [offLight)   1 per light: (pos, intensity)
@@ -168,7 +168,7 @@ template <bool COUNT, bool LDS_OBJECTS>
 __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   extern __shared__ float4 s_obj[];
   const int Ns = P.numSpheres, Ne = P.numEllipsoids;
-  const int nGroups = (Ns + 3) >> 2; // trips of the sphere loop: 4 spheres = 4 float4
+  const int nGroups = (Ns + 7) >> 3; // trips of the sphere loop: 8 spheres = 8 float4
   if (LDS_OBJECTS) {
     for (int i = threadIdx.x; i < P.imageFloat4s; i += blockDim.x) s_obj[i] = P.image[i];
     __syncthreads();
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
   unsigned int cGroups = 0, cSlow = 0;  // wave-level: 4-sphere trips, trips that left the fast path
   unsigned int cExact = 0;              // rays this lane sent to the exact routine
-  unsigned long long cycRefill = 0, cycSpheres = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
+  unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
 #define PT_PHASE(ACC) if (COUNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
   if (COUNT) tPhase = __builtin_amdgcn_s_memtime();
 
@@ -387,19 +387,27 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   }
       if (__ballot(fastLane) != 0ull) {
         for (int g = 0; g < nGroups; ++g) {
-          const float4 a0 = PT_PAIR(4 * g), b0 = PT_PAIR(4 * g + 1), a1 = PT_PAIR(4 * g + 2), b1 = PT_PAIR(4 * g + 3);
-          f2 d0, d1;
+          const float4 a0 = PT_PAIR(8 * g), b0 = PT_PAIR(8 * g + 1), a1 = PT_PAIR(8 * g + 2), b1 = PT_PAIR(8 * g + 3);
+          const float4 a2 = PT_PAIR(8 * g + 4), b2 = PT_PAIR(8 * g + 5), a3 = PT_PAIR(8 * g + 6), b3 = PT_PAIR(8 * g + 7);
+          f2 d0, d1, d2, d3;
           PT_PAIR_DISC(a0, b0, d0)
           PT_PAIR_DISC(a1, b1, d1)
+          PT_PAIR_DISC(a2, b2, d2)
+          PT_PAIR_DISC(a3, b3, d3)
           // finite rays and a finite scene give finite discriminants (no NaN to lose in max)
-          const float m = __builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y));
+          const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y)),
+                                          __builtin_fmaxf(__builtin_fmaxf(d2.x, d2.y), __builtin_fmaxf(d3.x, d3.y)));
           if (COUNT) cGroups++;
           if (__ballot(m >= 0.0f) != 0ull) {
             if (COUNT) cSlow++;
-            PT_ENQUEUE(4 * g, d0.x)
-            PT_ENQUEUE(4 * g + 1, d0.y)
-            PT_ENQUEUE(4 * g + 2, d1.x)
-            PT_ENQUEUE(4 * g + 3, d1.y)
+            PT_ENQUEUE(8 * g, d0.x)
+            PT_ENQUEUE(8 * g + 1, d0.y)
+            PT_ENQUEUE(8 * g + 2, d1.x)
+            PT_ENQUEUE(8 * g + 3, d1.y)
+            PT_ENQUEUE(8 * g + 4, d2.x)
+            PT_ENQUEUE(8 * g + 5, d2.y)
+            PT_ENQUEUE(8 * g + 6, d3.x)
+            PT_ENQUEUE(8 * g + 7, d3.y)
           }
         }
         if (qTail > qHead) { drain(qTail - qHead); qHead = qTail; }
@@ -417,6 +425,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // of a chunk and the shader's sequential acceptance (including its NaN
       // behaviour: a NaN t is accepted and then voids the upper bound for the
       // next sphere) is reproduced chunk by chunk.
+      PT_PHASE(cycSpheres)
       unsigned long long todo = __ballot(special);
       const unsigned long long finiteMask = (P.sceneHuge == 0) ? __ballot(finiteRay) : 0ull;
       while (todo != 0ull) {
@@ -446,13 +455,37 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           // Each lane keeps the best of its own spheres; one reduction at the end.
           float myBest = __builtin_inff();
           int myIdx = -1;
-          for (int base = 0; base < Ns; base += 64) {
-            const int j = base + lane;
-            const bool inb = j < Ns;
-            PT_EXACT_SPHERE(j, inb)
-            const float v = (t0 < tMin) ? t1 : t0;
-            if (root && !(v < tMin) && v <= myBest) { myBest = v; myIdx = j; }
-            if (COUNT) roots += root ? 1u : 0u;
+          // four chunks per trip: the loads go out together and the four root
+          // chains are independent, which hides their latency
+          for (int base = 0; base < Ns; base += 256) {
+            float4 sp4[4];
+            bool in4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = base + 64 * u + lane;
+              in4[u] = j < Ns;
+              sp4[u] = P.spheres[in4[u] ? j : 0];
+            }
+            float hb4[4], disc4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float ocx = eox - sp4[u].x, ocy = eoy - sp4[u].y, ocz = eoz - sp4[u].z;
+              hb4[u] = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
+              const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+              const float cc = __builtin_fmaf(-sp4[u].w, sp4[u].w, dd);
+              disc4[u] = __builtin_fmaf(hb4[u], hb4[u], -cc);
+            }
+            float sq4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sq4[u] = __builtin_sqrtf(disc4[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const bool root = in4[u] && !(disc4[u] < 0.0f);
+              const float t0 = -hb4[u] - sq4[u], t1 = -hb4[u] + sq4[u];
+              const float v = (t0 < tMin) ? t1 : t0;
+              if (root && !(v < tMin) && v <= myBest) { myBest = v; myIdx = base + 64 * u + lane; }
+              if (COUNT) roots += root ? 1u : 0u;
+            }
           }
           unsigned long long key = ((unsigned long long)__float_as_uint(myBest) << 32) |
                                    (unsigned long long)(~((unsigned int)myIdx + 1u));
@@ -502,7 +535,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       }
     }
 
-    PT_PHASE(cycSpheres)
+    PT_PHASE(cycExact)
     // hitEllipsoid (raytrace.comp:171-210), after the spheres as in traceRay
     if (live) {
       const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
@@ -879,6 +912,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       atomicAdd(&P.counters[14], cycSpheres);
       atomicAdd(&P.counters[15], cycEll);
       atomicAdd(&P.counters[16], cycShade);
+      atomicAdd(&P.counters[17], cycExact);
     }
     // wave reduction, then one atomic per counter per wave
     unsigned long long v[13];

@@ -95,6 +95,7 @@ COUNTER_NAMES = (
     "cyc_spheres",
     "cyc_ellipsoids",
     "cyc_shade",
+    "cyc_exact",
 )
 N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 

@@ -42,6 +42,50 @@ __global__ void __launch_bounds__(1024) loop_kernel(const float4 *pairs, int nGr
         if (__ballot(m >= 0.0f) != 0ull) hits++;
         a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
       }
+    } else if (V == 5) { // ping-pong prefetch: no register copies (nGroups even)
+      float4 a0 = s_obj[0], b0 = s_obj[1], a1 = s_obj[2], b1 = s_obj[3];
+      for (int g = 0; g < nGroups; g += 2) {
+        const float4 c0 = s_obj[4 * g + 4], e0 = s_obj[4 * g + 5], c1 = s_obj[4 * g + 6], e1 = s_obj[4 * g + 7];
+        {
+          f2 d0, d1;
+          PAIR_DISC(a0, b0, d0) PAIR_DISC(a1, b1, d1)
+          const float m = __builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y));
+          if (__ballot(m >= 0.0f) != 0ull) hits++;
+        }
+        const int gn = (g + 2 < nGroups) ? g + 2 : 0;
+        a0 = s_obj[4 * gn]; b0 = s_obj[4 * gn + 1]; a1 = s_obj[4 * gn + 2]; b1 = s_obj[4 * gn + 3];
+        {
+          f2 d0, d1;
+          PAIR_DISC(c0, e0, d0) PAIR_DISC(c1, e1, d1)
+          const float m = __builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y));
+          if (__ballot(m >= 0.0f) != 0ull) hits++;
+        }
+      }
+    } else if (V == 6) { // 8 spheres per trip, one sign test per trip
+      for (int g = 0; g < nGroups; g += 2) {
+        const float4 a0 = s_obj[4 * g], b0 = s_obj[4 * g + 1], a1 = s_obj[4 * g + 2], b1 = s_obj[4 * g + 3];
+        const float4 c0 = s_obj[4 * g + 4], e0 = s_obj[4 * g + 5], c1 = s_obj[4 * g + 6], e1 = s_obj[4 * g + 7];
+        f2 d0, d1, d2, d3;
+        PAIR_DISC(a0, b0, d0) PAIR_DISC(a1, b1, d1) PAIR_DISC(c0, e0, d2) PAIR_DISC(c1, e1, d3)
+        const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y)),
+                                        __builtin_fmaxf(__builtin_fmaxf(d2.x, d2.y), __builtin_fmaxf(d3.x, d3.y)));
+        if (__ballot(m >= 0.0f) != 0ull) hits++;
+      }
+    } else if (V == 7) { // two rays per lane: sphere data read once for both
+      const f2 PX = mk2(ox + 0.5f, ox + 0.5f), PY = mk2(oy + 0.25f, oy + 0.25f), PZ = OZ;
+      const f2 EX = mk2(dx, dx), EY = mk2(dy + 0.1f, dy + 0.1f), EZ = DZ;
+      for (int g = 0; g < nGroups; ++g) {
+        const float4 a0 = s_obj[4 * g], b0 = s_obj[4 * g + 1], a1 = s_obj[4 * g + 2], b1 = s_obj[4 * g + 3];
+        f2 d0, d1, d2, d3;
+        PAIR_DISC(a0, b0, d0) PAIR_DISC(a1, b1, d1)
+        {
+          const f2 OX = PX, OY = PY, OZ = PZ, DX = EX, DY = EY, DZ = EZ;
+          PAIR_DISC(a0, b0, d2) PAIR_DISC(a1, b1, d3)
+        }
+        const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y)),
+                                        __builtin_fmaxf(__builtin_fmaxf(d2.x, d2.y), __builtin_fmaxf(d3.x, d3.y)));
+        if (__ballot(m >= 0.0f) != 0ull) hits++;
+      }
     } else if (V == 4) {
       for (int g = 0; g < nGroups; ++g) {
         float m = -1.0f;
@@ -117,5 +161,8 @@ int main() {
   if (run<2>("LDS reads only", d, nGroups, p.multiProcessorCount, o)) return 1;
   if (run<3>("LDS + packed, prefetch", d, nGroups, p.multiProcessorCount, o)) return 1;
   if (run<4>("LDS + scalar math", d, nGroups, p.multiProcessorCount, o)) return 1;
+  if (run<5>("LDS + packed, ping-pong", d, nGroups, p.multiProcessorCount, o)) return 1;
+  if (run<6>("LDS + packed, 8 per trip", d, nGroups, p.multiProcessorCount, o)) return 1;
+  if (run<7>("2 rays/lane (per 2 trips)", d, nGroups, p.multiProcessorCount, o)) return 1;
   return 0;
 }
