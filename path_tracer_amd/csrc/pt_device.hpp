@@ -306,6 +306,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       const bool unitDir = __builtin_fabsf(dLen2 - 1.0f) <= 2.0e-3f;
       const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0;
       const bool special = live && !fastLane;
+      // lanes whose ellipsoid roots can be deferred too: finite ray with a usable direction
+      const bool qLane = live && finiteRay && P.sceneHuge == 0 && dLen2 >= 1.0e-30f;
       if (COUNT && live) cRays++;
       if (COUNT && special) cExact++;
       // lanes without a finite ray get one that can never produce a candidate
@@ -411,13 +413,6 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           }
         }
         if (qTail > qHead) { drain(qTail - qHead); qHead = qTail; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned long long kbest = w_slot[lane];
-        const unsigned int widx = ~(unsigned int)kbest - 1u; // none -> 0xFFFFFFFF
-        if (fastLane && widx < (unsigned int)Ns) {
-          bestT = __uint_as_float((unsigned int)(kbest >> 32));
-          bestIdx = (int)widx;
-        }
       }
 
       // Exact routine for the few rays the fast path must not (non-finite) or
@@ -528,16 +523,105 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
 #undef PT_EXACT_SPHERE
         if (lane == owner) {
-          bestT = C;
-          bestIdx = win;
+          if (qLane) { // finite: C is a plain t >= tMin; the ellipsoid queue continues from it
+            if (win >= 0)
+              w_slot[lane] = ((unsigned long long)__float_as_uint(C) << 32) | (unsigned long long)(~((unsigned int)win + 1u));
+          } else {
+            bestT = C;
+            bestIdx = win;
+          }
           if (COUNT) cRoots += roots;
+        }
+      }
+      PT_PHASE(cycExact)
+
+      // hitEllipsoid (raytrace.comp:171-210), after the spheres as in traceRay.
+      // Same scheme as the spheres: the wave-uniform loop computes every lane's
+      // discriminant, roots go through the queue and are evaluated 64 at a time.
+      // (a = |dirScaled|^2 is part of the test, so non-unit directions are fine.)
+      auto drainE = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned int e = w_queue[(qHead + lane) & 127];
+        const bool on = lane < n;
+        const int owner = on ? (int)(e & 63u) : lane;
+        const int j = on ? (int)(e >> 6) - Ns : 0;
+        const V3 eo = mk3(__shfl(rO.x, owner), __shfl(rO.y, owner), __shfl(rO.z, owner));
+        const V3 ed = mk3(__shfl(rD.x, owner), __shfl(rD.y, owner), __shfl(rD.z, owner));
+        const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
+        const V3 nq = xyz(e2), nq2 = xyz(e3);
+        const V3 oc = rotate_q(sub3(eo, xyz(e0)), nq, nq2, e0.w);
+        const V3 dir = rotate_q(ed, nq, nq2, e0.w);
+        const V3 invR = xyz(e1);
+        const V3 ocS = mul3(oc, invR), dS = mul3(dir, invR);
+        const float a = dot3(dS, dS);
+        const float hb = dot3(ocS, dS);
+        const float c = dot3(ocS, ocS) - 1.0f;
+        const float disc = __builtin_fmaf(hb, hb, -(a * c));
+        const float sq = __builtin_sqrtf(disc);
+        float t = (-hb - sq) / a;
+        if (t < tMin) t = (-hb + sq) / a;
+        if (on && !(t < tMin)) {
+          const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) |
+                                         (unsigned long long)(~((unsigned int)(Ns + j) + 1u));
+          atomicMin(&w_slot[owner], key);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      };
+      if (Ne > 0 && __ballot(qLane) != 0ull) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // four ellipsoids per trip: their discriminant chains are independent
+        for (int j0 = 0; j0 < Ne; j0 += 4) {
+          float disc4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = (j0 + u < Ne) ? j0 + u : Ne - 1;
+            const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
+            const V3 nq = xyz(e2), nq2 = xyz(e3);
+            const V3 oc = rotate_q(sub3(rO, xyz(e0)), nq, nq2, e0.w);
+            const V3 dir = rotate_q(rD, nq, nq2, e0.w);
+            const V3 invR = xyz(e1);
+            const V3 ocS = mul3(oc, invR), dS = mul3(dir, invR);
+            const float a = dot3(dS, dS);
+            const float hb = dot3(ocS, dS);
+            const float c = dot3(ocS, ocS) - 1.0f;
+            disc4[u] = __builtin_fmaf(hb, hb, -(a * c));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            const bool cand = qLane && j < Ne && disc4[u] >= 0.0f;
+            const unsigned long long cm = __ballot(cand);
+            if (cm != 0ull) {
+              const int pre = __popcll(cm & laneMaskLt);
+              if (cand) {
+                w_queue[(qTail + pre) & 127] = (unsigned int)lane | ((unsigned int)(Ns + j) << 6);
+                if (COUNT) cERoots++;
+              }
+              qTail += __popcll(cm);
+              if (qTail - qHead >= 64) { drainE(64); qHead += 64; }
+            }
+          }
+        }
+        if (qTail > qHead) { drainE(qTail - qHead); qHead = qTail; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (qLane) {
+        const unsigned long long kbest = w_slot[lane];
+        const unsigned int widx = ~(unsigned int)kbest - 1u; // none -> 0xFFFFFFFF
+        if (widx < (unsigned int)(Ns + Ne)) {
+          bestT = __uint_as_float((unsigned int)(kbest >> 32));
+          bestIdx = (int)widx;
         }
       }
     }
 
-    PT_PHASE(cycExact)
-    // hitEllipsoid (raytrace.comp:171-210), after the spheres as in traceRay
-    if (live) {
+    // Rays that are not finite keep the shader's sequential loop, NaN rules and all.
+    const bool seqEll = live && !(__builtin_fabsf(rO.x) <= 1.0e9f && __builtin_fabsf(rO.y) <= 1.0e9f &&
+                                  __builtin_fabsf(rO.z) <= 1.0e9f && __builtin_fabsf(rD.x) <= 1.0e9f &&
+                                  __builtin_fabsf(rD.y) <= 1.0e9f && __builtin_fabsf(rD.z) <= 1.0e9f &&
+                                  P.sceneHuge == 0 && dot3(rD, rD) >= 1.0e-30f);
+
+    if (__ballot(seqEll) != 0ull && seqEll) {
       const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
       const float tMin = kEpsilon;
       for (int j = 0; j < Ne; ++j) {
