@@ -165,6 +165,19 @@ class Runner:
         self.r.shutdown()
 
 
+def measured_traffic(workload: str):
+    """HBM-side bytes per launch of the timed kernel for this workload, from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE need a pass each and cannot be collected from inside this process).  The workloads
+    are deterministic, so the per-launch figure of the profiled build carries over; None when no profile exists."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f).get(workload)
+        return None if t is None else float(t["fetch_bytes"] + t["write_bytes"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def roofline_for(cnt, kernel_ms: float, traffic=None):
     flop = cnt[4] * FLOP_PER_SPHERE_TEST + cnt[5] * FLOP_PER_ELLIPSOID_TEST
     vox_bytes = cnt[6] * BYTES_PER_VOXEL_SAMPLE
@@ -283,7 +296,8 @@ def main():
                        "rays_per_frame": rays, "split": f"interleaved {BAND_ROWS}-row bands, RCCL gather to rank 0"
                        if n_gpus > 1 else "single GPU", "device": dev_name, "compute_units": cus,
                        "launch": {"blocks": launch[0], "threads": launch[1], "lds_bytes": launch[2]}},
-            "roofline": roofline_for(cnt / max(n_gpus, 1), kernel_ms) if n_gpus == 1 else None,
+            "roofline": roofline_for(cnt / max(n_gpus, 1), kernel_ms,
+                                     measured_traffic(args.workload) if args.scale == 1.0 else None) if n_gpus == 1 else None,
         }
         if check is not None:
             result["config"]["gathered_frame_equals_single_gpu_frame"] = check
@@ -303,7 +317,7 @@ def main():
             d, e = rr.timed(steps, 1)
             rr.close()
             extras[name] = {"ms_per_frame": round(d / steps * 1e3, 4), "Mrays_per_s": round(c[0] / (d / steps) / 1e6, 2),
-                            "rays_per_frame": float(c[0]), "roofline": roofline_for(c, e / steps)}
+                            "rays_per_frame": float(c[0]), "roofline": roofline_for(c, e / steps, measured_traffic(name))}
             if name == "c4":
                 extras[name]["Msamples_per_s"] = round(c[6] / (d / steps) / 1e6, 2)
         result["workloads"] = extras

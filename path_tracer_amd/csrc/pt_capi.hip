@@ -89,13 +89,16 @@ struct PtRenderer {
   int numSpheres = 0, numEllipsoids = 0, numMaterials = 0, numLights = 0, numVolumes = 0;
   int numEmSpheres = 0, numEmEllipsoids = 0;
   DevBuf dSpheres, dImage, dVoxels;
-  int imageFloat4s = 0, offEll = 0, offMat = 0, offLight = 0, offEmS = 0, offEmE = 0, offMatIdx = 0, matIdxEllBase = 0;
+  int imageFloat4s = 0, offEll = 0, offEllPair = 0, offMat = 0, offLight = 0, offEmS = 0, offEmE = 0, offMatIdx = 0, matIdxEllBase = 0;
   bool voxelsUploaded = false;
   size_t voxelBytes = 0;
   PtGPUVolumetricData volume0{};
 
   // output
-  DevBuf dRgba8, dF32, dScratch; // dScratch: tile counter (4 B), counters (PT_CNT_COUNT x 8 B) at +64
+  DevBuf dRgba8, dF32, dScratch; // dScratch: see kScratchBytes
+  DevBuf dTileOrder;             // 3 x numTiles tile indices (one list per cost class)
+  bool tileOrder = true;
+  int tune = 0;
   void *extRgba8 = nullptr, *extF32 = nullptr;
   bool floatOutput = true;
   int objectSource = 0;
@@ -109,6 +112,9 @@ struct PtRenderer {
 };
 
 namespace {
+
+// dScratch: class counts (3 x 4 B) at +16, counters (PT_CNT_COUNT x 8 B) at +64, tile-ticket counters at +256
+constexpr size_t kScratchBytes = 256 + (size_t)ptdev::kTicketGroups * ptdev::kTicketStride * sizeof(unsigned int);
 
 int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {
   if (bandCount <= 1) return height;
@@ -125,11 +131,11 @@ int ensure_outputs(PtRenderer *r) {
   size_t px = (size_t)r->width * (size_t)std::max(r->localRows, 1);
   if (!r->extRgba8) PT_HIP_CHECK(r->dRgba8.reserve(px * 4));
   if (r->floatOutput && !r->extF32 && !r->extRgba8) PT_HIP_CHECK(r->dF32.reserve(px * 16));
-  PT_HIP_CHECK(r->dScratch.reserve(256));
+  PT_HIP_CHECK(r->dScratch.reserve(kScratchBytes));
   return PT_OK;
 }
 
-int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
+int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: the kernel's MODE (0 plain, 1 counting, 2 phase cycles)
   if (!r || !pc) return fail(PT_ERR_INVALID, "pt_render: null argument");
   if (!r->sceneValid) return fail(PT_ERR_STATE, "pt_render: pt_update_scene has not been called");
   if (pc->numSpheres < 0 || pc->numSpheres > r->numSpheres || pc->numEllipsoids < 0 ||
@@ -189,6 +195,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
   P.image = (const float4 *)r->dImage.p;
   P.imageFloat4s = r->imageFloat4s;
   P.offEll = r->offEll;
+  P.offEllPair = r->offEllPair;
   P.offMat = r->offMat;
   P.offLight = r->offLight;
   P.offEmS = r->offEmS;
@@ -198,17 +205,22 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
   P.voxels = (const uint8_t *)r->dVoxels.p;
   P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8.p);
   P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr));
-  P.tileCounter = (unsigned int *)r->dScratch.p;
+  P.tileCounter = (unsigned int *)((char *)r->dScratch.p + 256);
   P.counters = (unsigned long long *)((char *)r->dScratch.p + 64);
 
   if (P.numTiles <= 0) return PT_OK;
+  if (r->tileOrder) {
+    PT_HIP_CHECK(r->dTileOrder.reserve((size_t)P.numTiles * 3 * sizeof(int)));
+    P.tileOrder = (int *)r->dTileOrder.p;
+    P.classCount = (unsigned int *)((char *)r->dScratch.p + 16);
+  }
 
   // Launch geometry: persistent workgroups, 16 waves per CU.  Objects are
   // staged in LDS when they fit (<= 80 KiB: two 512-thread groups per CU;
   // <= 160 KiB: one 1024-thread group); otherwise read from global memory.
   // LDS per workgroup: the object image (if staged) + 1 KiB of queue/result scratch per wave.
   size_t objBytes = (size_t)r->imageFloat4s * sizeof(float4);
-  bool useLds = objBytes + 16 * 1024 <= 160 * 1024;
+  bool useLds = objBytes + 16 * 1024 + 1024 <= 160 * 1024; // + per-wave scratch + the copy of the frame constants
   if (r->objectSource == 1 && !useLds)
     return fail(PT_ERR_INVALID, "pt_render: scene does not fit the 160 KiB LDS (PT_OPT_OBJECT_SOURCE=1)");
   if (r->objectSource == 2) useLds = false;
@@ -217,31 +229,29 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, bool counted) {
   else if (objBytes <= 32 * 1024) { threads = 256; blocksPerCu = 4; }   // 4 x (32 + 4) KiB
   else if (objBytes <= 64 * 1024) { threads = 512; blocksPerCu = 2; }   // 2 x (64 + 8) KiB
   else { threads = 1024; blocksPerCu = 1; }                             // 1 x (<=144 + 16) KiB
-  size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024;
+  size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15); // + the kernel's copy of the frame constants
   P.sceneHuge = r->sceneHuge ? 1 : 0;
+  P.tune = r->tune;
   long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
   int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
 
-  PT_HIP_CHECK(hipMemsetAsync(r->dScratch.p, 0, counted ? 256 : 4, r->stream));
-  dim3 grid(blocks), block(threads);
-  if (counted) {
-    if (useLds) {
-      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<true, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-      hipLaunchKernelGGL((ptdev::pt_render_kernel<true, true>), grid, block, ldsBytes, r->stream, P);
-    } else {
-      hipLaunchKernelGGL((ptdev::pt_render_kernel<true, false>), grid, block, ldsBytes, r->stream, P);
-    }
-  } else {
-    if (useLds) {
-      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<false, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-      hipLaunchKernelGGL((ptdev::pt_render_kernel<false, true>), grid, block, ldsBytes, r->stream, P);
-    } else {
-      hipLaunchKernelGGL((ptdev::pt_render_kernel<false, false>), grid, block, ldsBytes, r->stream, P);
-    }
+  PT_HIP_CHECK(hipMemsetAsync(r->dScratch.p, 0, kScratchBytes, r->stream));
+  if (P.tileOrder) {
+    hipLaunchKernelGGL(ptdev::pt_tile_order_kernel, dim3((P.numTiles + 255) / 256), dim3(256), 0, r->stream, P);
+    PT_HIP_CHECK(hipGetLastError());
   }
+  dim3 grid(blocks), block(threads);
+#define PT_LAUNCH(MODE_)                                                                                     \
+  if (useLds) {                                                                                              \
+    PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, true>,                     \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));            \
+    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, true>), grid, block, ldsBytes, r->stream, P);         \
+  } else {                                                                                                   \
+    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, false>), grid, block, ldsBytes, r->stream, P);        \
+  }
+  if (mode == 1) { PT_LAUNCH(1) } else if (mode == 2) { PT_LAUNCH(2) } else { PT_LAUNCH(0) }
+#undef PT_LAUNCH
   PT_HIP_CHECK(hipGetLastError());
   r->lastBlocks = blocks;
   r->lastThreads = threads;
@@ -296,7 +306,7 @@ void pt_destroy(PtRenderer *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch};
+  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch, &r->dTileOrder};
   for (DevBuf *b : bufs) b->release();
   if (r->evBegin) (void)hipEventDestroy(r->evBegin);
   if (r->evEnd) (void)hipEventDestroy(r->evEnd);
@@ -369,6 +379,19 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     img.push_back(make_float4(1.0f / e.radii[0], 1.0f / e.radii[1], 1.0f / e.radii[2], maxR));
     img.push_back(make_float4(-e.rotation[0], -e.rotation[1], -e.rotation[2], 0.0f));
     img.push_back(make_float4(-2.0f * e.rotation[0], -2.0f * e.rotation[1], -2.0f * e.rotation[2], 0.0f));
+  }
+  // The same fields once more, two ellipsoids side by side, for the packed discriminant loop.
+  const int offEllPair = (int)img.size();
+  for (int p = 0; 2 * p < num_ellipsoids; ++p) {
+    const PtGPUEllipsoid &a = ellipsoids[2 * p];
+    const PtGPUEllipsoid &b = ellipsoids[std::min(2 * p + 1, num_ellipsoids - 1)];
+    img.push_back(make_float4(a.center[0], b.center[0], a.center[1], b.center[1]));
+    img.push_back(make_float4(a.center[2], b.center[2], a.rotation[3], b.rotation[3]));
+    img.push_back(make_float4(1.0f / a.radii[0], 1.0f / b.radii[0], 1.0f / a.radii[1], 1.0f / b.radii[1]));
+    img.push_back(make_float4(1.0f / a.radii[2], 1.0f / b.radii[2], -a.rotation[0], -b.rotation[0]));
+    img.push_back(make_float4(-a.rotation[1], -b.rotation[1], -a.rotation[2], -b.rotation[2]));
+    img.push_back(make_float4(-2.0f * a.rotation[0], -2.0f * b.rotation[0], -2.0f * a.rotation[1], -2.0f * b.rotation[1]));
+    img.push_back(make_float4(-2.0f * a.rotation[2], -2.0f * b.rotation[2], 0.0f, 0.0f));
   }
   const int offMat = (int)img.size();
   for (int i = 0; i < num_materials; ++i) {
@@ -450,6 +473,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   r->numEmEllipsoids = nEmE;
   r->imageFloat4s = (int)img.size();
   r->offEll = offEll;
+  r->offEllPair = offEllPair;
   r->offMat = offMat;
   r->offLight = offLight;
   r->offEmS = offEmS;
@@ -466,14 +490,21 @@ int pt_reset_voxels(PtRenderer *r) {
   return PT_OK;
 }
 
-int pt_render(PtRenderer *r, const PtPushConstants *pc) { return launch_frame(r, pc, false); }
+int pt_render(PtRenderer *r, const PtPushConstants *pc) { return launch_frame(r, pc, 0); }
 
 int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters) {
   if (!counters) return fail(PT_ERR_INVALID, "pt_render_counted: counters is null");
-  int rc = launch_frame(r, pc, true);
+  int rc = launch_frame(r, pc, 1);
   if (rc != PT_OK) return rc;
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
   PT_HIP_CHECK(hipMemcpy(counters, (char *)r->dScratch.p + 64, PT_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  // the per-phase cycle sums come from a second frame drawn by the production code with timers only
+  rc = launch_frame(r, pc, 2);
+  if (rc != PT_OK) return rc;
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  uint64_t cyc[PT_CNT_COUNT];
+  PT_HIP_CHECK(hipMemcpy(cyc, (char *)r->dScratch.p + 64, sizeof cyc, hipMemcpyDeviceToHost));
+  for (int i = PT_CNT_CYC_REFILL; i < PT_CNT_COUNT; ++i) counters[i] = cyc[i];
   return PT_OK;
 }
 
@@ -594,6 +625,8 @@ int pt_set_option(PtRenderer *r, int option, int value) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_option: renderer is null");
   switch (option) {
   case PT_OPT_FLOAT_OUTPUT: r->floatOutput = value != 0; return PT_OK;
+  case PT_OPT_TILE_ORDER: r->tileOrder = value != 0; return PT_OK;
+  case 100: r->tune = value; return PT_OK; // experiment switches, not part of the interface
   case PT_OPT_OBJECT_SOURCE:
     if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: object source must be 0, 1 or 2");
     r->objectSource = value;

@@ -32,6 +32,8 @@ constexpr float kMaxDistance = 1e10f; // raytrace.comp:94
 constexpr float kEpsilon = 0.001f;    // raytrace.comp:95
 constexpr int kTileDim = 8;           // pixels per tile edge: one 8x8 tile = one refill of a whole wave
 constexpr int kTilePixels = kTileDim * kTileDim;
+constexpr int kTicketGroups = 32;     // tile-ticket counters (power of two), one per group of workgroups
+constexpr int kTicketStride = 32;     // unsigned ints between two counters: one 128-byte line each
 
 struct FrameParams {
   // camera basis, computed once per frame on the host with the same float
@@ -57,6 +59,9 @@ struct FrameParams {
   //   [0)          sphere pairs, 2 float4 per pair (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1),
   //                padded with copies of the last sphere to a multiple of 8 spheres
   //   [offEll)     4 per ellipsoid: (c,qw) (1/radii,maxRadius) (-q.xyz,0) (-2q.xyz,0)
+  //   [offEllPair) 7 per pair of ellipsoids, every field as (first, second) of the pair:
+  //                (cx,cy) (cz,qw) (1/rx,1/ry) (1/rz,-qx) (-qy,-qz) (-2qx,-2qy) (-2qz,0); an odd
+  //                count is padded with a copy of the last ellipsoid
   //   [offMat)     5 per material, as GPUMaterial
   //   [offLight)   1 per light: (pos, intensity)
   //   [offEmS)     3 per emissive sphere, ascending sphere index:
@@ -65,14 +70,20 @@ struct FrameParams {
   //   [offMatIdx)  uint16 material index per sphere, then per ellipsoid
   const float4 *image;
   int imageFloat4s;
-  int offEll, offMat, offLight, offEmS, offEmE, offMatIdx;
+  int offEll, offEllPair, offMat, offLight, offEmS, offEmE, offMatIdx;
   int matIdxEllBase;         // element offset of the ellipsoid part of the uint16 table
   const float4 *spheres;     // (cx, cy, cz, r), one per sphere, global memory
   const uint8_t *voxels;
   uint32_t *outRgba8;
   float4 *outF32;           // may be null
-  unsigned int *tileCounter;
+  unsigned int *tileCounter;    // kTicketGroups counters, kTicketStride apart
   unsigned long long *counters; // PT_CNT_COUNT slots, instrumented kernel only
+  // Optional drawing order (null: tiles are drawn in index order).  tileOrder holds
+  // three lists of numTiles entries each, one per cost class; classCount[c] is the
+  // length of list c.  Tickets run through class 2, then 1, then 0.
+  int *tileOrder;
+  unsigned int *classCount;
+  int tune; // experiment switches (bit mask), 0 in production; bit 0: no wave priorities
 };
 
 struct V3 { float x, y, z; };
@@ -111,6 +122,23 @@ __device__ __forceinline__ float glfract(float x) { return x - __builtin_floorf(
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Three-vectors of pairs: the same operations as V3, on two objects at once.
+struct P3 { f2 x, y, z; };
+__device__ __forceinline__ P3 mkp3(f2 x, f2 y, f2 z) { P3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ P3 splat3(V3 v) { return mkp3(mk2(v.x, v.x), mk2(v.y, v.y), mk2(v.z, v.z)); }
+__device__ __forceinline__ P3 add3p(P3 a, P3 b) { return mkp3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ P3 sub3p(P3 a, P3 b) { return mkp3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ P3 mul3p(P3 a, P3 b) { return mkp3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f2 dot3p(P3 a, P3 b) { return fma2(a.z, b.z, fma2(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ P3 cross3p(P3 a, P3 b) {
+  return mkp3(fma2(a.y, b.z, -(a.z * b.y)), fma2(a.z, b.x, -(a.x * b.z)), fma2(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ P3 madd3p(P3 a, f2 s, P3 b) { return mkp3(fma2(s, b.x, a.x), fma2(s, b.y, a.y), fma2(s, b.z, a.z)); }
+__device__ __forceinline__ P3 rotate_qp(P3 v, P3 q, P3 q2, f2 qw) {
+  P3 t = cross3p(q2, v);
+  return add3p(madd3p(v, qw, t), cross3p(q, t));
+}
 
 // rotateByQuaternion with q.xyz and 2*q.xyz supplied (raytrace.comp:99-108):
 // t = 2*cross(q, v) == cross(2q, v) exactly; v' = (v + qw*t) + cross(q, t)
@@ -154,6 +182,104 @@ __device__ __forceinline__ uint32_t unorm8(float c) {
   return (uint32_t)(int)__builtin_rintf(c * 255.0f);
 }
 
+// Pixel w (0..63) of tile `tile`: x, local row ly (row of the compact band-major
+// frame) and full-frame row gy.  False when the pixel lies outside the frame.
+__device__ __forceinline__ bool tile_pixel(const FrameParams &P, int tile, int w, int &x, int &ly, int &gy) {
+  const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+  x = tx * kTileDim + (w & 7);
+  ly = ty * kTileDim + (w >> 3);
+  const int band = ly / P.bandRows;
+  gy = (band * P.bandCount + P.bandIndex) * P.bandRows + (ly - band * P.bandRows);
+  return x < P.width && ly < P.localRows && gy < P.height;
+}
+
+// createCameraRay for pixel (x, gy) (raytrace.comp:121-140 with main()'s uv, :692-700)
+__device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) {
+  float uvx = (float)x / (float)P.width;
+  float uvy = (float)gy / (float)P.height;
+  uvy = 1.0f - uvy;
+  const float sx = ((uvx - 0.5f) * P.aspect) * P.fov;
+  const float sy = (uvy - 0.5f) * P.fov;
+  return normalize3(madd3(madd3(ld3(P.fwd), sx, ld3(P.right)), sy, ld3(P.up)));
+}
+
+// Drawing-order pass: one thread per tile looks at what the tile's centre pixel
+// sees first and files the tile under a cost class: 2 = a surface that bounces
+// the path on (long ray chains), 1 = any other surface or the volume box, 0 =
+// background.  The render kernel draws class 2 first and class 0 last, so the
+// pixels with the longest chains of rays are started early and the frame does
+// not end on them.  Only the ORDER of the tiles depends on this pass; what is
+// drawn for each pixel does not, so nothing here needs the render kernel's
+// exact arithmetic.
+__global__ void __launch_bounds__(256) pt_tile_order_kernel(const FrameParams P) {
+  const int tileRaw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inRange = tileRaw < P.numTiles;
+  const int tile = inRange ? tileRaw : P.numTiles - 1;
+  int x, ly, gy;
+  tile_pixel(P, tile, 4 * 8 + 4, x, ly, gy);
+  if (x >= P.width) x = P.width - 1;
+  if (gy >= P.height) gy = P.height - 1;
+  const V3 o = ld3(P.cam), d = camera_dir(P, x, gy);
+  float best = kMaxDistance;
+  int bestIdx = -1;
+  for (int i = 0; i < P.numSpheres; ++i) {
+    const float4 sp = P.spheres[i];
+    const V3 oc = sub3(o, xyz(sp));
+    const float hb = dot3(oc, d);
+    const float disc = hb * hb - (dot3(oc, oc) - sp.w * sp.w);
+    if (disc >= 0.0f) {
+      const float sq = __builtin_sqrtf(disc);
+      float t = -hb - sq;
+      if (t < kEpsilon) t = -hb + sq;
+      if (t >= kEpsilon && t <= best) { best = t; bestIdx = i; }
+    }
+  }
+  for (int j = 0; j < P.numEllipsoids; ++j) {
+    const float4 e0 = P.image[P.offEll + 4 * j], e1 = P.image[P.offEll + 4 * j + 1];
+    const float4 e2 = P.image[P.offEll + 4 * j + 2], e3 = P.image[P.offEll + 4 * j + 3];
+    const V3 oc = mul3(rotate_q(sub3(o, xyz(e0)), xyz(e2), xyz(e3), e0.w), xyz(e1));
+    const V3 dir = mul3(rotate_q(d, xyz(e2), xyz(e3), e0.w), xyz(e1));
+    const float a = dot3(dir, dir), hb = dot3(oc, dir), c = dot3(oc, oc) - 1.0f;
+    const float disc = hb * hb - a * c;
+    if (disc >= 0.0f) {
+      const float sq = __builtin_sqrtf(disc);
+      float t = (-hb - sq) / a;
+      if (t < kEpsilon) t = (-hb + sq) / a;
+      if (t >= kEpsilon && t <= best) { best = t; bestIdx = P.numSpheres + j; }
+    }
+  }
+  int cls = 0;
+  if (bestIdx >= 0) {
+    const unsigned short *mi = (const unsigned short *)(P.image + P.offMatIdx);
+    const int m = bestIdx < P.numSpheres ? mi[bestIdx] : mi[P.matIdxEllBase + (bestIdx - P.numSpheres)];
+    const float reflectivity = P.image[P.offMat + 5 * m + 1].w, transparency = P.image[P.offMat + 5 * m + 2].x;
+    cls = (P.maxBounces > 1 && (reflectivity > 0.01f || transparency > 0.01f)) ? 2 : 1;
+  }
+  if (cls == 0 && P.numVolumes > 0) {
+    // slab test against the volume box (raytrace.comp:519-533), any overlap in front of the eye
+    float t0 = 0.0f, t1 = kMaxDistance;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    for (int a = 0; a < 3; ++a) {
+      const float inv = 1.0f / dd[a];
+      const float ta = (P.boxMin[a] - oo[a]) * inv, tb = (P.boxMax[a] - oo[a]) * inv;
+      t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+      t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+    }
+    if (t0 <= t1) cls = 1;
+  }
+  // one atomic per wave and class; lanes take consecutive places behind it
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int c = 0; c < 3; ++c) {
+    const unsigned long long m = __ballot(inRange && cls == c);
+    if (m == 0ull) continue;
+    unsigned int base = 0;
+    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&P.classCount[c], (unsigned int)__popcll(m));
+    base = (unsigned int)__shfl((int)base, (int)__builtin_ctzll(m));
+    if (inRange && cls == c) P.tileOrder[c * P.numTiles + (int)(base + (unsigned int)__popcll(m & lt))] = tile;
+  }
+}
+
 // Lane states: which kind of ray the lane has in flight.
 enum : int {
   ST_IDLE = 0,       // wants a pixel
@@ -164,8 +290,14 @@ enum : int {
   ST_EM_ELLIPSOID = 5 // emissive-ellipsoid occlusion ray         (raytrace.comp:469)
 };
 
-template <bool COUNT, bool LDS_OBJECTS>
+// MODE 0: the production kernel.  MODE 1: also counts rays, tests, roots and
+// wave trips (what the oracle counts, for parity checks and the bench's ray
+// count).  MODE 2: production code plus per-phase cycle sums per wave (kept
+// apart from MODE 1, whose extra registers would distort the timing).
+template <int MODE, bool LDS_OBJECTS>
 __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
+  constexpr bool COUNT = MODE == 1;
+  constexpr bool PHASES = MODE == 2;
   extern __shared__ float4 s_obj[];
   const int Ns = P.numSpheres, Ne = P.numEllipsoids;
   const int nGroups = (Ns + 7) >> 3; // trips of the sphere loop: 8 spheres = 8 float4
@@ -177,6 +309,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #define PT_IMG(i) (LDS_OBJECTS ? s_obj[(i)] : g_img[(i)])
 #define PT_PAIR(i) PT_IMG(i)
 #define PT_ELL(j, k) PT_IMG(P.offEll + 4 * (j) + (k))
+#define PT_ELLP(p, k) PT_IMG(P.offEllPair + 7 * (p) + (k))
 #define PT_MAT(m, k) PT_IMG(P.offMat + 5 * (m) + (k))
 #define PT_LIGHT(i) PT_IMG(P.offLight + (i))
 #define PT_EMS(e, k) PT_IMG(P.offEmS + 3 * (e) + (k))
@@ -185,6 +318,18 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   ((int)(LDS_OBJECTS ? ((const unsigned short *)(s_obj + P.offMatIdx))[(i)]                 \
                      : ((const unsigned short *)(g_img + P.offMatIdx))[(i)]))
 
+  // Frame constants that are not needed in the intersection loops are read
+  // from an LDS copy where they are used, instead of living in registers for
+  // the whole kernel.
+  FrameParams *const paramsLds =
+      (FrameParams *)(s_obj + (LDS_OBJECTS ? P.imageFloat4s : 0) + 64 * (int)(blockDim.x >> 6));
+  {
+    const int __attribute__((address_space(4))) *ka =
+        (const int __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int i = threadIdx.x; i < (int)(sizeof(FrameParams) / 4); i += blockDim.x) ((int *)paramsLds)[i] = ka[i];
+    __syncthreads();
+  }
+  const FrameParams &L = *paramsLds;
   const int lane = threadIdx.x & 63;
   const unsigned long long laneMaskLt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   // per-wave scratch behind the object image: 128-entry candidate ring + 64 result slots (1 KiB)
@@ -194,8 +339,15 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned long long *const w_slot = (unsigned long long *)(w_area + 32);
 
   // wave-uniform tile pool
+  const int homeGroup = (int)(blockIdx.x & (kTicketGroups - 1));
+  int groupsTried = 0; // ticket groups this wave has found drained
   int poolNext = 0, poolEnd = 0;
   bool exhausted = false;
+  unsigned int nClass2 = 0, nClass1 = 0; // drawing order: tickets [0,n2) class 2, [n2,n2+n1) class 1, rest class 0
+  if (P.tileOrder) {
+    nClass2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)P.classCount[2]);
+    nClass1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)P.classCount[1]);
+  }
 
   // per-lane pixel / path state
   int state = ST_IDLE;
@@ -219,46 +371,67 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned int cGroups = 0, cSlow = 0;  // wave-level: 4-sphere trips, trips that left the fast path
   unsigned int cExact = 0;              // rays this lane sent to the exact routine
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
-#define PT_PHASE(ACC) if (COUNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
-  if (COUNT) tPhase = __builtin_amdgcn_s_memtime();
+#define PT_PHASE(ACC) if (PHASES) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
+  if (PHASES) tPhase = __builtin_amdgcn_s_memtime();
 
   for (;;) {
     // ------------------------------------------------------------------
     // 1. refill idle lanes from the wave's tile pool
     // ------------------------------------------------------------------
-    unsigned long long idleMask = __ballot(state == ST_IDLE);
-    while (idleMask != 0ull && !exhausted) {
-      if (poolNext == poolEnd) {
-        unsigned int t = 0;
-        if (lane == 0) t = atomicAdd(P.tileCounter, 1u);
-        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= (unsigned int)P.numTiles) { exhausted = true; break; }
-        poolNext = (int)t * kTilePixels;
-        poolEnd = poolNext + kTilePixels;
-      }
-      const int avail = poolEnd - poolNext;
+    // Idle lanes take the next pixels of the pool in lane order; when the pool
+    // runs out part-way, the rest continue in the next tile (fetched first).
+    const unsigned long long idleMask = __ballot(state == ST_IDLE);
+    if (idleMask != 0ull && !(exhausted && poolNext == poolEnd)) {
       const int nIdle = __popcll(idleMask);
-      const int take = avail < nIdle ? avail : nIdle;
+      const int avail = poolEnd - poolNext;
+      int nextBase = -1; // first pixel of the following tile, if one is needed and left
+      if (nIdle > avail && !exhausted) {
+        // Tickets come from kTicketGroups counters instead of one: group g owns
+        // tickets g, g + G, g + 2G, ...  A single counter would see one same-address
+        // atomic per tile from every wave of the chip, and those queue for
+        // microseconds each.  A wave draws from its own group until that is
+        // drained, then from the next group that still has tickets (peeked with a
+        // plain load first, so drained groups cost no atomics).
+        unsigned int t = 0xFFFFFFFFu;
+        while (groupsTried < kTicketGroups) {
+          const int g = (homeGroup + groupsTried) & (kTicketGroups - 1);
+          const unsigned int owned = ((unsigned int)P.numTiles + (unsigned int)(kTicketGroups - 1 - g)) / kTicketGroups;
+          unsigned int *ctr = P.tileCounter + g * kTicketStride;
+          bool drained = owned == 0u;
+          if (!drained && groupsTried > 0)
+            drained = (unsigned int)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned int *)ctr) >= owned;
+          if (!drained) {
+            unsigned int a = 0;
+            if (lane == 0) a = atomicAdd(ctr, 1u);
+            a = (unsigned int)__builtin_amdgcn_readfirstlane((int)a);
+            if (a < owned) { t = (unsigned int)g + (unsigned int)kTicketGroups * a; break; }
+          }
+          ++groupsTried;
+        }
+        if (t >= (unsigned int)P.numTiles) {
+          exhausted = true;
+        } else {
+          if (P.tileOrder) {
+            const int at = t < nClass2 ? 2 * P.numTiles + (int)t
+                           : t < nClass2 + nClass1 ? P.numTiles + (int)(t - nClass2) : (int)(t - nClass2 - nClass1);
+            t = (unsigned int)__builtin_amdgcn_readfirstlane(P.tileOrder[at]);
+          }
+          nextBase = (int)t * kTilePixels;
+        }
+      }
       const int rank = __popcll(idleMask & laneMaskLt);
-      if (state == ST_IDLE && rank < take) {
-        const int p = poolNext + rank;
-        const int tile = p / kTilePixels, q = p % kTilePixels;
-        const int tx = tile % P.tilesX, ty = tile / P.tilesX;
-        const int sub = q >> 6, w = q & 63;
-        const int x = tx * kTileDim + (sub & 1) * 8 + (w & 7);
-        const int ly = ty * kTileDim + (sub >> 1) * 8 + (w >> 3);
-        const int band = ly / P.bandRows;
-        const int gy = (band * P.bandCount + P.bandIndex) * P.bandRows + (ly - band * P.bandRows);
-        if (x < P.width && ly < P.localRows && gy < P.height) {
+      int p = -1;
+      if (state == ST_IDLE) {
+        if (rank < avail) p = poolNext + rank;
+        else if (nextBase >= 0) p = nextBase + (rank - avail); // nIdle <= 64 = one tile
+      }
+      if (p >= 0) {
+        int x, ly, gy;
+        if (tile_pixel(L, p / kTilePixels, p % kTilePixels, x, ly, gy)) {
           // main() + createCameraRay (raytrace.comp:686-700, 121-140)
-          float uvx = (float)x / (float)P.width;
-          float uvy = (float)gy / (float)P.height;
-          uvy = 1.0f - uvy;
-          float sx = ((uvx - 0.5f) * P.aspect) * P.fov;
-          float sy = (uvy - 0.5f) * P.fov;
-          curO = ld3(P.cam);
-          curD = normalize3(madd3(madd3(ld3(P.fwd), sx, ld3(P.right)), sy, ld3(P.up)));
-          outIdx = ly * P.width + x;
+          curO = ld3(L.cam);
+          curD = camera_dir(L, x, gy);
+          outIdx = ly * L.width + x;
           fin = mk3(0, 0, 0);
           thr = 1.0f;
           bounce = 0;
@@ -267,10 +440,20 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           if (COUNT) cPath++;
         }
       }
-      poolNext += take;
-      idleMask = __ballot(state == ST_IDLE);
+      if (nIdle > avail) {
+        if (nextBase >= 0) { poolNext = nextBase + (nIdle - avail); poolEnd = nextBase + kTilePixels; }
+        else poolNext = poolEnd;
+      } else {
+        poolNext += nIdle;
+      }
     }
     if (__ballot(state != ST_IDLE) == 0ull) break;
+    // Waves that carry bounced paths, or that are finishing their last pixels,
+    // hold the longest chains of dependent rays: let them issue first.
+    if (!(P.tune & 1)) {
+      if (exhausted || __ballot(state != ST_IDLE && bounce >= 1) != 0ull) __builtin_amdgcn_s_setprio(3);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     PT_PHASE(cycRefill)
 
     // ------------------------------------------------------------------
@@ -569,36 +752,39 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       };
       if (Ne > 0 && __ballot(qLane) != 0ull) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // four ellipsoids per trip: their discriminant chains are independent
-        for (int j0 = 0; j0 < Ne; j0 += 4) {
-          float disc4[4];
+        // two ellipsoids per trip, one packed instruction for both (hitEllipsoid's
+        // operations, raytrace.comp:173-187, on each half)
+        const P3 RO = splat3(rO), RD = splat3(rD);
+        for (int p = 0; 2 * p < Ne; ++p) {
+          const float4 g0 = PT_ELLP(p, 0), g1 = PT_ELLP(p, 1), g2 = PT_ELLP(p, 2), g3 = PT_ELLP(p, 3);
+          const float4 g4 = PT_ELLP(p, 4), g5 = PT_ELLP(p, 5), g6 = PT_ELLP(p, 6);
+          const P3 ctr = mkp3(mk2(g0.x, g0.y), mk2(g0.z, g0.w), mk2(g1.x, g1.y));
+          const f2 qw = mk2(g1.z, g1.w);
+          const P3 invR = mkp3(mk2(g2.x, g2.y), mk2(g2.z, g2.w), mk2(g3.x, g3.y));
+          const P3 nq = mkp3(mk2(g3.z, g3.w), mk2(g4.x, g4.y), mk2(g4.z, g4.w));
+          const P3 nq2 = mkp3(mk2(g5.x, g5.y), mk2(g5.z, g5.w), mk2(g6.x, g6.y));
+          const P3 oc = rotate_qp(sub3p(RO, ctr), nq, nq2, qw);
+          const P3 dir = rotate_qp(RD, nq, nq2, qw);
+          const P3 ocS = mul3p(oc, invR), dS = mul3p(dir, invR);
+          const f2 a = dot3p(dS, dS);
+          const f2 hb = dot3p(ocS, dS);
+          const f2 c = dot3p(ocS, ocS) - mk2(1.0f, 1.0f);
+          const f2 disc = fma2(hb, hb, -(a * c));
+          if (__ballot(qLane && __builtin_fmaxf(disc.x, disc.y) >= 0.0f) != 0ull) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int j = (j0 + u < Ne) ? j0 + u : Ne - 1;
-            const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
-            const V3 nq = xyz(e2), nq2 = xyz(e3);
-            const V3 oc = rotate_q(sub3(rO, xyz(e0)), nq, nq2, e0.w);
-            const V3 dir = rotate_q(rD, nq, nq2, e0.w);
-            const V3 invR = xyz(e1);
-            const V3 ocS = mul3(oc, invR), dS = mul3(dir, invR);
-            const float a = dot3(dS, dS);
-            const float hb = dot3(ocS, dS);
-            const float c = dot3(ocS, ocS) - 1.0f;
-            disc4[u] = __builtin_fmaf(hb, hb, -(a * c));
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            const bool cand = qLane && j < Ne && disc4[u] >= 0.0f;
-            const unsigned long long cm = __ballot(cand);
-            if (cm != 0ull) {
-              const int pre = __popcll(cm & laneMaskLt);
-              if (cand) {
-                w_queue[(qTail + pre) & 127] = (unsigned int)lane | ((unsigned int)(Ns + j) << 6);
-                if (COUNT) cERoots++;
+            for (int u = 0; u < 2; ++u) {
+              const int j = 2 * p + u;
+              const bool cand = qLane && j < Ne && (u == 0 ? disc.x : disc.y) >= 0.0f;
+              const unsigned long long cm = __ballot(cand);
+              if (cm != 0ull) {
+                const int pre = __popcll(cm & laneMaskLt);
+                if (cand) {
+                  w_queue[(qTail + pre) & 127] = (unsigned int)lane | ((unsigned int)(Ns + j) << 6);
+                  if (COUNT) cERoots++;
+                }
+                qTail += __popcll(cm);
+                if (qTail - qHead >= 64) { drainE(64); qHead += 64; }
               }
-              qTail += __popcll(cm);
-              if (qTail - qHead >= 64) { drainE(64); qHead += 64; }
             }
           }
         }
@@ -721,12 +907,12 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           // --- rayMarchVolume(currentRay, hit ? rec.t : MAX_DISTANCE, 0) (:534-585) ---
           float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
           float volumeAlpha = 0.0f;
-          if (P.numVolumes > 0) {
+          if (L.numVolumes > 0) {
             const float maxDist = hitAny ? bestT : kMaxDistance;
             // intersectBox (:519-532)
             const V3 invDir = mk3(1.0f / (curD.x + 1e-8f), 1.0f / (curD.y + 1e-8f), 1.0f / (curD.z + 1e-8f));
-            const V3 t0 = mul3(sub3(ld3(P.boxMin), curO), invDir);
-            const V3 t1 = mul3(sub3(ld3(P.boxMax), curO), invDir);
+            const V3 t0 = mul3(sub3(ld3(L.boxMin), curO), invDir);
+            const V3 t1 = mul3(sub3(ld3(L.boxMax), curO), invDir);
             const V3 tmn = mk3(glmin(t0.x, t1.x), glmin(t0.y, t1.y), glmin(t0.z, t1.z));
             const V3 tmx = mk3(glmax(t0.x, t1.x), glmax(t0.y, t1.y), glmax(t0.z, t1.z));
             float tNear = glmax(glmax(tmn.x, tmn.y), tmn.z);
@@ -734,23 +920,23 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             if (tFar >= tNear && tFar > 0.0f) {
               tNear = glmax(tNear, 0.0f);
               tFar = glmin(tFar, maxDist);
-              const float4 m4 = PT_MAT(P.volMaterial, 4);
+              const float4 m4 = PT_MAT(L.volMaterial, 4);
               const float absorptionCoeff = m4.w;
-              const float rxf = (float)P.res[0], ryf = (float)P.res[1], rzf = (float)P.res[2];
-              const int rx = P.res[0], ry = P.res[1], rz = P.res[2];
+              const float rxf = (float)L.res[0], ryf = (float)L.res[1], rzf = (float)L.res[2];
+              const int rx = L.res[0], ry = L.res[1], rz = L.res[2];
               float t = tNear;
               float acc = 0.0f;
               int stepCount = 0;
               while (t < tFar && stepCount < 500) {
                 // sampleVolume (:485-517), nearest neighbour
                 const V3 pos = madd3(curO, t, curD);
-                const V3 rel = sub3(pos, ld3(P.volPos));
+                const V3 rel = sub3(pos, ld3(L.volPos));
                 float density = 0.0f;
-                if (!(rel.x < P.v0[0] || rel.y < P.v0[1] || rel.z < P.v0[2] ||
-                      rel.x > P.v1[0] || rel.y > P.v1[1] || rel.z > P.v1[2])) {
-                  const float ux = (rel.x - P.v0[0]) / P.extent[0];
-                  const float uy = (rel.y - P.v0[1]) / P.extent[1];
-                  const float uz = (rel.z - P.v0[2]) / P.extent[2];
+                if (!(rel.x < L.v0[0] || rel.y < L.v0[1] || rel.z < L.v0[2] ||
+                      rel.x > L.v1[0] || rel.y > L.v1[1] || rel.z > L.v1[2])) {
+                  const float ux = (rel.x - L.v0[0]) / L.extent[0];
+                  const float uy = (rel.y - L.v0[1]) / L.extent[1];
+                  const float uz = (rel.z - L.v0[2]) / L.extent[2];
                   int ix = (int)(ux * rxf), iy = (int)(uy * ryf), iz = (int)(uz * rzf);
                   ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix);
                   iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
@@ -783,8 +969,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const V3 unitDir = normalize3(curD);
             const float t = 0.5f * (unitDir.y + 1.0f);
             const float omt = 1.0f - t;
-            const V3 bg = mk3(P.bgBottom[0] * omt + P.bgTop[0] * t, P.bgBottom[1] * omt + P.bgTop[1] * t,
-                              P.bgBottom[2] * omt + P.bgTop[2] * t);
+            const V3 bg = mk3(L.bgBottom[0] * omt + L.bgTop[0] * t, L.bgBottom[1] * omt + L.bgTop[1] * t,
+                              L.bgBottom[2] * omt + L.bgTop[2] * t);
             fin = add3(fin, scale3(bg, thr));
             step = GO_FINISH;
             break;
@@ -819,7 +1005,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const int shaderFunctionIndex = (int)m2.z;
           if (shaderFunctionIndex != 0) {
             if (shaderFunctionIndex == 1) { // rainbow: color 0 + emissive
-              lit = add3(mk3(0, 0, 0), rainbow_emissive(hitP, emissiveStrength, P.time));
+              lit = add3(mk3(0, 0, 0), rainbow_emissive(hitP, emissiveStrength, L.time));
               step = GO_AFTER_LIGHTING;
             } else if (shaderFunctionIndex == 2) { // toon.glsl:11
               lit = scale3(surfaceColor, m0.w);
@@ -839,7 +1025,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         case GO_NEXT_LIGHT:
         case GO_NEXT_TOON_LIGHT: {
-          if (k < P.numLights) { // getShadowFactor (:243-253)
+          if (k < L.numLights) { // getShadowFactor (:243-253)
             const float4 L = PT_LIGHT(k);
             const V3 lightVec = sub3(xyz(L), hitP);
             const float distToLight = length3(lightVec);
@@ -864,10 +1050,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         case GO_NEXT_EM_SPHERE: { // raytrace.comp:367-443, over the precomputed emissive list
           step = GO_NEXT_EM_ELLIPSOID;
-          while (k < P.numEmSpheres) {
+          while (k < L.numEmSpheres) {
             const float4 s = PT_EMS(k, 0), sm = PT_EMS(k, 1), sx = PT_EMS(k, 2);
             const int si = __float_as_int(sx.y);
-            if (si >= Ns) { k = P.numEmSpheres; break; }
+            if (si >= Ns) { k = L.numEmSpheres; break; }
             float sphereEmissive = sm.w;
             V3 emissiveColor = xyz(sm);
             const V3 toSphere = sub3(xyz(s), hitP);
@@ -878,13 +1064,13 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             if (sphereShaderIndex != 0) { // :377-414
               const V3 approximateHitPoint = sub3(xyz(s), scale3(dirToSphere, s.w));
               if (sphereShaderIndex == 1) {
-                emissiveColor = rainbow_emissive(approximateHitPoint, sphereEmissive, P.time);
+                emissiveColor = rainbow_emissive(approximateHitPoint, sphereEmissive, L.time);
               } else if (sphereShaderIndex == 2) {
                 // toon keeps result.emissive = surfaceColor * emissiveStrength (toon.glsl:45-47);
                 // its light loop only feeds result.color, which this caller drops, so the
                 // shadow rays it would issue are elided (but still counted as issued)
                 emissiveColor = scale3(xyz(sm), sphereEmissive);
-                if (COUNT) { cLight += (unsigned int)P.numLights; cRays += (unsigned int)P.numLights; }
+                if (COUNT) { cLight += (unsigned int)L.numLights; cRays += (unsigned int)L.numLights; }
               } else {
                 emissiveColor = mk3(0, 0, 0);
               }
@@ -912,10 +1098,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         case GO_NEXT_EM_ELLIPSOID: { // raytrace.comp:445-480
           step = GO_AFTER_LIGHTING;
-          while (k < P.numEmEllipsoids) {
+          while (k < L.numEmEllipsoids) {
             const float4 e0 = PT_EME(k, 0), em = PT_EME(k, 1), ex = PT_EME(k, 2);
             const int ei = __float_as_int(ex.x);
-            if (ei >= Ne) { k = P.numEmEllipsoids; break; }
+            if (ei >= Ne) { k = L.numEmEllipsoids; break; }
             const V3 toE = sub3(xyz(e0), hitP);
             const float distE = length3(toE);
             const V3 dirE = div3s(toE, distE);
@@ -963,7 +1149,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           if (cont) {
             bounce++;
             // loop head of traceIterative (:605-606)
-            if (bounce < P.maxBounces && !(length3(mk3(thr, thr, thr)) < 0.001f)) {
+            if (bounce < L.maxBounces && !(length3(mk3(thr, thr, thr)) < 0.001f)) {
               rO = curO; rD = curD; rTmax = kMaxDistance;
               state = ST_PATH;
               if (COUNT) cPath++;
@@ -974,8 +1160,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         case GO_FINISH: { // main() :703-704
           const float r = glclamp(fin.x, 0.0f, 1.0f), g = glclamp(fin.y, 0.0f, 1.0f), b = glclamp(fin.z, 0.0f, 1.0f);
+          if (!(P.tune & 4)) {
           P.outRgba8[outIdx] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
           if (P.outF32) P.outF32[outIdx] = make_float4(r, g, b, 1.0f);
+          }
           state = ST_IDLE;
           step = GO_EMITTED;
           break;
@@ -990,14 +1178,14 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   }
 #undef PT_PHASE
 
+  if (PHASES && lane == 0) {
+    atomicAdd(&P.counters[13], cycRefill);
+    atomicAdd(&P.counters[14], cycSpheres);
+    atomicAdd(&P.counters[15], cycEll);
+    atomicAdd(&P.counters[16], cycShade);
+    atomicAdd(&P.counters[17], cycExact);
+  }
   if (COUNT) {
-    if (lane == 0) {
-      atomicAdd(&P.counters[13], cycRefill);
-      atomicAdd(&P.counters[14], cycSpheres);
-      atomicAdd(&P.counters[15], cycEll);
-      atomicAdd(&P.counters[16], cycShade);
-      atomicAdd(&P.counters[17], cycExact);
-    }
     // wave reduction, then one atomic per counter per wave
     unsigned long long v[13];
     v[0] = cRays; v[1] = cPath; v[2] = cLight; v[3] = cEmis;

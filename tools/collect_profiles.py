@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of one tools/round_profile.sh run into profiles/.
+
+    tools/collect_profiles.py gpurun_out/<tag> r1      # writes profiles/r1_*.{txt,json}
+
+Outputs (all text, small):
+  <round>_bench.json          the bench.py line of that run
+  <round>_kernel_trace.txt    rocprofv3 --kernel-trace --stats of the same bench command: per-kernel calls / total / average
+  <round>_pmc.txt             per-dispatch PMC sums for workloads c2, c3, c4 (SQ pass, FETCH_SIZE pass, WRITE_SIZE pass)
+  <round>_traffic.json        FETCH_SIZE / WRITE_SIZE per launch of the timed kernel, in bytes (rocprofv3 reports KiB)
+"""
+import glob
+import io
+import json
+import os
+import sqlite3
+import sys
+from contextlib import redirect_stdout
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import pmc_summary  # noqa: E402
+
+
+def kernel_counter(db, counter, kernel_like="pt_render_kernel<false"):
+    con = sqlite3.connect(db)
+    acc, disp = 0.0, set()
+    for k, did, cname, val in con.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+        if kernel_like in k and cname == counter:
+            acc += val
+            disp.add(did)
+    return acc / max(len(disp), 1)
+
+
+def main():
+    src, rnd = sys.argv[1], sys.argv[2]
+    out = os.path.join(os.path.dirname(HERE), "profiles")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(src, "bench.json")) as f:
+        line = [l for l in f.read().splitlines() if l.startswith("{")][-1]
+    with open(os.path.join(out, f"{rnd}_bench.json"), "w") as f:
+        f.write(line + "\n")
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        sys.argv = ["pmc_summary", os.path.join(src, "trace_bench")]
+        pmc_summary.main()
+    with open(os.path.join(out, f"{rnd}_kernel_trace.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras\n")
+        f.write("# (default workload c2: 12 launches of pt_render_kernel<false,...> = 2 warm-up + 10 timed; <true,...> is the\n")
+        f.write("#  instrumented, untimed counting launch)\n")
+        f.write(buf.getvalue())
+        for wl in ("c3", "c4"):
+            d = os.path.join(src, f"trace_{wl}")
+            if os.path.isdir(d):
+                b2 = io.StringIO()
+                with redirect_stdout(b2):
+                    sys.argv = ["pmc_summary", d]
+                    pmc_summary.main()
+                f.write(f"# same, --workload {wl} --steps 3 --warmup 1\n" + b2.getvalue())
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+            if os.path.isdir(d):
+                sys.argv = ["pmc_summary", d]
+                print(f"#### {os.path.basename(d)}")
+                pmc_summary.main()
+    text = "\n".join(l for l in buf.getvalue().splitlines()
+                     if "rocclr" not in l and not (l.startswith("   ") and float(l.split()[-1]) < 1e4))
+    with open(os.path.join(out, f"{rnd}_pmc.txt"), "w") as f:
+        f.write("# one rocprofv3 --pmc pass per block; bench.py --workload <wl> --steps 3 --warmup 1 --no-extras --no-cpu\n")
+        f.write("# FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; <true,...> is the instrumented (untimed) launch\n")
+        f.write(text + "\n")
+    traffic = {}
+    for wl in ("c2", "c3", "c4"):
+        fdb = glob.glob(os.path.join(src, f"pmc_fetch_{wl}", "*_results.db"))
+        wdb = glob.glob(os.path.join(src, f"pmc_write_{wl}", "*_results.db"))
+        if fdb and wdb:
+            traffic[wl] = {"fetch_bytes": kernel_counter(fdb[0], "FETCH_SIZE") * 1024.0,
+                           "write_bytes": kernel_counter(wdb[0], "WRITE_SIZE") * 1024.0}
+    for name in (f"{rnd}_traffic.json", "traffic.json"):  # traffic.json = the latest, read by bench.py
+        with open(os.path.join(out, name), "w") as f:
+            json.dump(traffic, f, indent=1)
+            f.write("\n")
+    print("wrote", sorted(os.listdir(out)))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,9 +10,12 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2"
 timeout -k 10 600 $BENCH > $out/bench.json 2> $out/bench.err || { echo bench failed; tail -5 $out/bench.err; exit 1; }
-timeout -s KILL 600 rocprofv3 --kernel-trace --stats -d $out/trace_bench -o t -- $BENCH --no-cpu > $out/trace_bench.log 2>&1 || { echo trace failed; exit 1; }
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats -d $out/trace_bench -o t -- $BENCH --no-cpu --no-extras > $out/trace_bench.log 2>&1 || { echo trace failed; exit 1; }
 for wl in c2 c3 c4; do
   B="python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --no-extras --no-cpu"
+  if [ $wl != c2 ]; then
+    timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/trace_$wl -o t -- $B > $out/trace_$wl.log 2>&1 || { echo trace $wl failed; exit 1; }
+  fi
   timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $out/pmc_sq_$wl -o p -- $B > $out/pmc_sq_$wl.log 2>&1 || { echo pmc sq $wl failed; exit 1; }
   timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch_$wl -o p -- $B > $out/pmc_fetch_$wl.log 2>&1 || { echo pmc fetch $wl failed; exit 1; }
   timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write_$wl -o p -- $B > $out/pmc_write_$wl.log 2>&1 || { echo pmc write $wl failed; exit 1; }
