@@ -34,10 +34,12 @@ enum {
   PT_OPT_FLOAT_OUTPUT = 1, /* 1 (default): also keep the clamped float RGBA frame  */
   PT_OPT_OBJECT_SOURCE = 2, /* 0 auto, 1 objects staged in LDS, 2 objects read from
                                global memory (scenes too large for LDS use 2)      */
-  PT_OPT_TILE_ORDER = 3     /* 1 (default): a short pass before each frame sorts the
-                               8x8 tiles so that those whose pixels cast the longest
-                               chains of rays are drawn first; 0: index order.  The
-                               frame is the same either way.                        */
+  PT_OPT_TILE_ORDER = 3     /* 1: a short pass before each frame sorts the 8x8 tiles so
+                               that those whose pixels cast the longest chains of rays
+                               are drawn first; 0: index order; 2 (default): sorted
+                               when the scene has mirror or transparent objects and
+                               the pass is cheap next to the frame.  The frame is the
+                               same either way.                                      */
 };
 
 /* VulkanRenderer::initialize (reference include/VulkanRenderer.h:78,

@@ -97,7 +97,8 @@ struct PtRenderer {
   // output
   DevBuf dRgba8, dF32, dScratch; // dScratch: see kScratchBytes
   DevBuf dTileOrder;             // 3 x numTiles tile indices (one list per cost class)
-  bool tileOrder = true;
+  int tileOrder = 2;             // PT_OPT_TILE_ORDER: 0 off, 1 on, 2 decided per frame
+  bool sceneBounces = false;     // some object's material sends the path on (mirror or transparent)
   int tune = 0;
   void *extRgba8 = nullptr, *extF32 = nullptr;
   bool floatOutput = true;
@@ -209,7 +210,13 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   P.counters = (unsigned long long *)((char *)r->dScratch.p + 64);
 
   if (P.numTiles <= 0) return PT_OK;
-  if (r->tileOrder) {
+  // The ordering pass pays off when pixels differ a lot in the number of rays
+  // they cast (bounces) and looking at one pixel per tile is cheap next to the frame.
+  const bool orderTiles =
+      r->tileOrder == 1 ||
+      (r->tileOrder == 2 && r->sceneBounces && P.maxBounces > 1 &&
+       (long long)(pc->numSpheres + pc->numEllipsoids) * P.numTiles <= 50000000ll);
+  if (orderTiles) {
     PT_HIP_CHECK(r->dTileOrder.reserve((size_t)P.numTiles * 3 * sizeof(int)));
     P.tileOrder = (int *)r->dTileOrder.p;
     P.classCount = (unsigned int *)((char *)r->dScratch.p + 16);
@@ -232,6 +239,13 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15); // + the kernel's copy of the frame constants
   P.sceneHuge = r->sceneHuge ? 1 : 0;
   P.tune = r->tune;
+  {
+    // Break-even between one dense pass (about 7.5 instructions per sphere, whatever the number
+    // of rays) and the exact routine (about 0.31 per sphere + 150, per ray).
+    const double ns = (double)pc->numSpheres;
+    const int t = (int)(7.5 * ns / (0.31 * ns + 150.0));
+    P.sparseLanes = (r->tune >> 8) ? ((r->tune >> 8) & 0xff) - 1 : std::min(t, 32);
+  }
   long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
   int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
@@ -464,6 +478,10 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
 
   r->sceneHuge = sceneHuge;
+  r->sceneBounces = false;
+  auto bounces = [&](int m) { return materials[m].diffuseSpecularShiny[3] > 0.01f || materials[m].transparencyEmissive[0] > 0.01f; };
+  for (int i = 0; i < num_spheres && !r->sceneBounces; ++i) r->sceneBounces = bounces(spheres[i].materialIndex);
+  for (int i = 0; i < num_ellipsoids && !r->sceneBounces; ++i) r->sceneBounces = bounces(ellipsoids[i].materialIndex);
   r->numSpheres = num_spheres;
   r->numEllipsoids = num_ellipsoids;
   r->numMaterials = num_materials;
@@ -625,7 +643,10 @@ int pt_set_option(PtRenderer *r, int option, int value) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_option: renderer is null");
   switch (option) {
   case PT_OPT_FLOAT_OUTPUT: r->floatOutput = value != 0; return PT_OK;
-  case PT_OPT_TILE_ORDER: r->tileOrder = value != 0; return PT_OK;
+  case PT_OPT_TILE_ORDER:
+    if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_TILE_ORDER takes 0, 1 or 2");
+    r->tileOrder = value;
+    return PT_OK;
   case 100: r->tune = value; return PT_OK; // experiment switches, not part of the interface
   case PT_OPT_OBJECT_SOURCE:
     if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: object source must be 0, 1 or 2");

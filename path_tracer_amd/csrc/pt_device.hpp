@@ -83,6 +83,7 @@ struct FrameParams {
   // length of list c.  Tickets run through class 2, then 1, then 0.
   int *tileOrder;
   unsigned int *classCount;
+  int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
   int tune; // experiment switches (bit mask), 0 in production; bit 0: no wave priorities
 };
 
@@ -487,7 +488,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // it to the exact routine than to let it flood the candidate queue.
       const float dLen2 = dot3(rD, rD);
       const bool unitDir = __builtin_fabsf(dLen2 - 1.0f) <= 2.0e-3f;
-      const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0;
+      // With only a few rays left in the wave (the end of the frame), the dense
+      // loop would still cost a full pass; those rays go through the exact
+      // routine instead, whose cost is per ray.
+      const bool sparse = __popcll(__ballot(live)) <= P.sparseLanes;
+      const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0 && !sparse;
       const bool special = live && !fastLane;
       // lanes whose ellipsoid roots can be deferred too: finite ray with a usable direction
       const bool qLane = live && finiteRay && P.sceneHuge == 0 && dLen2 >= 1.0e-30f;
@@ -927,27 +932,51 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               float t = tNear;
               float acc = 0.0f;
               int stepCount = 0;
+              const V3 vpos = ld3(L.volPos), lo = ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
+              const uint8_t *__restrict__ vox = P.voxels;
+              // The march has no data-dependent exit, so four steps are taken per
+              // trip: their voxel loads are in flight together and the accumulation
+              // then runs in step order, exactly as one step per trip would.
               while (t < tFar && stepCount < 500) {
-                // sampleVolume (:485-517), nearest neighbour
-                const V3 pos = madd3(curO, t, curD);
-                const V3 rel = sub3(pos, ld3(L.volPos));
-                float density = 0.0f;
-                if (!(rel.x < L.v0[0] || rel.y < L.v0[1] || rel.z < L.v0[2] ||
-                      rel.x > L.v1[0] || rel.y > L.v1[1] || rel.z > L.v1[2])) {
-                  const float ux = (rel.x - L.v0[0]) / L.extent[0];
-                  const float uy = (rel.y - L.v0[1]) / L.extent[1];
-                  const float uz = (rel.z - L.v0[2]) / L.extent[2];
-                  int ix = (int)(ux * rxf), iy = (int)(uy * ryf), iz = (int)(uz * rzf);
-                  ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix);
-                  iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
-                  iz = iz < 0 ? 0 : (iz > rz - 1 ? rz - 1 : iz);
-                  const int index = ix + iy * rx + iz * rx * ry;
-                  density = (float)P.voxels[index] / 255.0f;
+                float ts[4];
+                int index[4];
+                int n = 1;
+                ts[0] = t;
+#pragma unroll
+                for (int u = 1; u < 4; ++u) {
+                  ts[u] = ts[u - 1] + 0.02f;
+                  if (n == u && ts[u] < tFar && stepCount + u < 500) n = u + 1;
                 }
-                const float sampleAlpha = density * absorptionCoeff;
-                acc = __builtin_fmaf(1.0f - acc, sampleAlpha, acc);
-                t += 0.02f;
-                stepCount++;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  // sampleVolume (:485-517), nearest neighbour
+                  const V3 pos = madd3(curO, ts[u], curD);
+                  const V3 rel = sub3(pos, vpos);
+                  index[u] = -1;
+                  if (u < n && !(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z)) {
+                    const float ux = (rel.x - lo.x) / ext.x;
+                    const float uy = (rel.y - lo.y) / ext.y;
+                    const float uz = (rel.z - lo.z) / ext.z;
+                    int ix = (int)(ux * rxf), iy = (int)(uy * ryf), iz = (int)(uz * rzf);
+                    ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix);
+                    iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
+                    iz = iz < 0 ? 0 : (iz > rz - 1 ? rz - 1 : iz);
+                    index[u] = ix + iy * rx + iz * rx * ry;
+                  }
+                }
+                unsigned int raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = index[u] >= 0 ? (unsigned int)vox[index[u]] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  if (u < n) {
+                    const float density = (float)raw[u] / 255.0f;
+                    const float sampleAlpha = density * absorptionCoeff;
+                    acc = __builtin_fmaf(1.0f - acc, sampleAlpha, acc);
+                  }
+                }
+                t = ts[n - 1] + 0.02f;
+                stepCount += n;
               }
               if (COUNT) cVoxel += (unsigned int)stepCount;
               // mix(vec3(-1), materialColor*acc, float(acc >= 1e-4)) = x*(1-a) + y*a
