@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (testing only; 1.0 = the named config)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4 side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4/C5 side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (gloo = host-memory rehearsal)")
@@ -320,6 +320,23 @@ def main():
                             "rays_per_frame": float(c[0]), "roofline": roofline_for(c, e / steps, measured_traffic(name))}
             if name == "c4":
                 extras[name]["Msamples_per_s"] = round(c[6] / (d / steps) / 1e6, 2)
+        if args.workload != "c5":
+            # 64 samples per pixel at 4K (C2's objects + the volume): one launch per sample, running mean on the device
+            sc = build_scene("c5")
+            rr = Runner(sc, 0, 1, local_rank)
+            c = rr.counters()  # sample 0 (the reference's sample)
+            spp = 64
+            rr.r.renderSamples(rr.pc, 0, 2)
+            rr.sync()
+            t0 = time.perf_counter()
+            rr.r.renderSamples(rr.pc, 0, spp)
+            rr.sync()
+            d = time.perf_counter() - t0
+            rr.close()
+            extras["c5"] = {"spp": spp, "ms_per_frame": round(d * 1e3, 3), "ms_per_sample": round(d / spp * 1e3, 4),
+                            "rays_sample0": float(c[0]), "Mrays_per_s": round(c[0] * spp / d / 1e6, 2),
+                            "note": "sub-pixel accumulation has no counterpart in the reference (one corner sample per "
+                                    "pixel); rays per sample taken from sample 0"}
         result["workloads"] = extras
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu:

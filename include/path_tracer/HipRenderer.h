@@ -149,6 +149,16 @@ public:
       std::cerr << "HipRenderer::render: " << pt_last_error() << std::endl;
   }
 
+  // Not in the reference: mean of sub-pixel samples firstSample .. firstSample + numSamples - 1
+  // (sample 0 is the reference's pixel-corner sample); keep continues the previous call's sum.
+  void renderSamples(const PushConstants &pushConstants, int firstSample, int numSamples, bool keep = false) {
+    if (!handle_) return;
+    PushConstants pc = pushConstants;
+    if (referenceBounceLimit) pc.maxDepth = 10;
+    if (pt_render_samples(handle_, reinterpret_cast<const PtPushConstants *>(&pc), firstSample, numSamples, keep ? 1 : 0) != PT_OK)
+      std::cerr << "HipRenderer::renderSamples: " << pt_last_error() << std::endl;
+  }
+
   // Waits for the frames enqueued so far.
   void present() {
     if (handle_ && pt_present(handle_) != PT_OK) std::cerr << "HipRenderer::present: " << pt_last_error() << std::endl;

@@ -34,6 +34,12 @@ enum {
   PT_OPT_FLOAT_OUTPUT = 1, /* 1 (default): also keep the clamped float RGBA frame  */
   PT_OPT_OBJECT_SOURCE = 2, /* 0 auto, 1 objects staged in LDS, 2 objects read from
                                global memory (scenes too large for LDS use 2)      */
+  PT_OPT_VOLUME_BRICKS = 4, /* 1 (default): the march reads a copy of volume 0 re-tiled
+                               into 8x8x8-voxel bricks (same voxels, better locality);
+                               0: it reads the linear x-fastest array as uploaded      */
+  PT_OPT_VOLUME_FILTER = 5, /* 0 (default): nearest-neighbour voxel sampling as in the
+                               reference (shaders/raytrace.comp:485-517); 1: trilinear
+                               (a quality mode of this library, no counterpart there)  */
   PT_OPT_TILE_ORDER = 3     /* 1: a short pass before each frame sorts the 8x8 tiles so
                                that those whose pixels cast the longest chains of rays
                                are drawn first; 0: index order; 2 (default): sorted
@@ -126,6 +132,16 @@ int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
 /* Run the instrumented kernel for one frame (same image, untimed) and return
  * the PT_CNT_* work counters. */
 int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters);
+
+/* Progressive accumulation (no counterpart in the reference, which draws one
+ * sample per pixel at the pixel corner and never calls its random(), reference
+ * shaders/raytrace.comp:117-119, 692-700).  Draws sub-pixel samples
+ * first_sample .. first_sample + num_samples - 1, one launch each, and leaves
+ * the mean of the clamped samples in the output frames.  Sample 0 is the
+ * reference's sample; sample s > 0 is offset inside the pixel by a
+ * counter-based hash of (pixel, s).  keep != 0 adds to the sum of the previous
+ * call instead of starting a new one.  pt_render is (0, 1, 0). */
+int pt_render_samples(PtRenderer *r, const PtPushConstants *pc, int first_sample, int num_samples, int keep);
 
 /* Device pointers of the current output frames (f32 may be NULL). */
 void *pt_device_rgba8(PtRenderer *r);

@@ -46,6 +46,10 @@ def lib():
         L.pto_render.restype = C.c_int
         L.pto_render.argtypes = [C.POINTER(_PtoScene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pto_render_ex.restype = C.c_int
+        L.pto_render_ex.argtypes = L.pto_render.argtypes + [C.POINTER(_PtoOptions)]
+        L.pto_sample_offset.restype = None
+        L.pto_sample_offset.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         fp = C.POINTER(C.c_float)
         L.pto_hit_sphere.restype = C.c_int
         L.pto_hit_sphere.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, fp, fp, fp]
@@ -62,6 +66,10 @@ def lib():
         L.pto_surface_shader.argtypes = [C.POINTER(_PtoScene), C.c_void_p, C.c_int, fp, fp, fp, C.c_int, fp]
         _lib = L
     return _lib
+
+
+class _PtoOptions(C.Structure):
+    _fields_ = [("volume_filter", C.c_int), ("first_sample", C.c_int), ("num_samples", C.c_int)]
 
 
 def _f3(v):
@@ -87,9 +95,19 @@ class _Held:
                            0 if self.vox is None else self.vox.size)
 
 
+def sample_offset(pixel: int, sample: int) -> Tuple[float, float]:
+    jx, jy = C.c_float(), C.c_float()
+    lib().pto_sample_offset(pixel, sample, C.byref(jx), C.byref(jy))
+    return jx.value, jy.value
+
+
 def render(scene, max_bounces: Optional[int] = None, rows: Optional[Tuple[int, int]] = None,
-           nthreads: int = 0, want_f32: bool = True):
-    """Returns (rgba8[H,W,4] uint8, f32[H,W,4] float32 or None, counters[8] uint64)."""
+           nthreads: int = 0, want_f32: bool = True, volume_filter: int = 0, first_sample: int = 0,
+           num_samples: int = 1):
+    """Returns (rgba8[H,W,4] uint8, f32[H,W,4] float32 or None, counters uint64).
+
+    volume_filter = 1 (trilinear) and num_samples > 1 (mean of jittered samples) are extensions
+    without a counterpart in the reference; the defaults restate the reference."""
     L = lib()
     held = _Held(scene)
     pc = scene.push_constants()
@@ -101,8 +119,10 @@ def render(scene, max_bounces: Optional[int] = None, rows: Optional[Tuple[int, i
     cnt = np.zeros(N_COUNTERS, dtype=np.uint64)
     if nthreads <= 0:
         nthreads = min(os.cpu_count() or 1, 16)
-    rc = L.pto_render(C.byref(held.c), pc.ctypes.data, W, H, mb, r0, r1,
-                      None if f32 is None else f32.ctypes.data, rgba.ctypes.data, cnt.ctypes.data, nthreads)
+    opt = _PtoOptions(volume_filter, first_sample, num_samples)
+    rc = L.pto_render_ex(C.byref(held.c), pc.ctypes.data, W, H, mb, r0, r1,
+                         None if f32 is None else f32.ctypes.data, rgba.ctypes.data, cnt.ctypes.data, nthreads,
+                         C.byref(opt))
     assert rc == 0
     return rgba, f32, cnt
 

@@ -88,6 +88,8 @@ typedef struct {
   const PtoScene *s;
   const PtPushConstants *pc;
   int width, height, max_bounces;
+  int volume_filter;             /* 0 nearest (the reference), 1 trilinear (extension) */
+  int first_sample, num_samples; /* accumulation (extension); 0, 1 = the reference's single sample */
   uint64_t cnt[PT_CNT_COUNT];
 } Ctx;
 
@@ -496,6 +498,41 @@ static float sampleVolume(Ctx *c, v3 worldPos, int volumeIndex) {
   uint32_t byteValue = 0;
   if (index >= 0 && (uint64_t)index < c->s->voxel_bytes && c->s->voxels)
     byteValue = c->s->voxels[index];
+  if (c->volume_filter == 1) {
+    /* Trilinear extension (no counterpart in the reference): voxel centres sit at
+     * (i + 0.5) / res; the sample point in voxel units is u * res - 0.5, clamped to
+     * [0, res - 1]; lerp(a, b, t) = fma(t, b - a, a) along x, then y, then z, on the
+     * byte values as floats; the result is divided by 255 like the nearest sample. */
+    float p[3] = {relPos.x * (float)res_x - 0.5f, relPos.y * (float)res_y - 0.5f, relPos.z * (float)res_z - 0.5f};
+    int res[3] = {res_x, res_y, res_z};
+    int i0[3], i1[3];
+    float f[3];
+    for (int a = 0; a < 3; a++) {
+      float hi = (float)(res[a] - 1);
+      float q = p[a] < 0.0f ? 0.0f : (p[a] > hi ? hi : p[a]);
+      if (q != q) q = 0.0f;
+      i0[a] = (int)q;
+      f[a] = q - (float)i0[a];
+      i1[a] = i0[a] + 1 > res[a] - 1 ? res[a] - 1 : i0[a] + 1;
+    }
+    float b[2][2][2];
+    for (int z = 0; z < 2; z++)
+      for (int y = 0; y < 2; y++)
+        for (int x = 0; x < 2; x++) {
+          int64_t id = (int64_t)(x ? i1[0] : i0[0]) + (int64_t)(y ? i1[1] : i0[1]) * res_x +
+                       (int64_t)(z ? i1[2] : i0[2]) * res_x * res_y;
+          uint32_t v = 0;
+          if (id >= 0 && (uint64_t)id < c->s->voxel_bytes && c->s->voxels) v = c->s->voxels[id];
+          b[z][y][x] = (float)v;
+        }
+    float c00 = fmaf(f[0], b[0][0][1] - b[0][0][0], b[0][0][0]);
+    float c10 = fmaf(f[0], b[0][1][1] - b[0][1][0], b[0][1][0]);
+    float c01 = fmaf(f[0], b[1][0][1] - b[1][0][0], b[1][0][0]);
+    float c11 = fmaf(f[0], b[1][1][1] - b[1][1][0], b[1][1][0]);
+    float c0 = fmaf(f[1], c10 - c00, c00);
+    float c1 = fmaf(f[1], c11 - c01, c01);
+    return fmaf(f[2], c1 - c0, c0) / 255.0f;
+  }
   return (float)byteValue / 255.0f;
 }
 
@@ -625,15 +662,36 @@ static inline uint8_t unorm8(float c) {
   return (uint8_t)(int)rintf(c * 255.0f);
 }
 
+/* Sub-pixel offset of sample `s` of pixel `pixel` (= y * width + x), in [0, 1)^2.
+ * Sample 0 is the reference's pixel-corner sample; the others come from a
+ * counter-based integer hash (extension, no counterpart in the reference). */
+void pto_sample_offset(uint32_t pixel, uint32_t s, float *jx, float *jy) {
+  if (s == 0) { *jx = 0.0f; *jy = 0.0f; return; }
+  uint32_t h = pixel * 0x9E3779B1u + s * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  *jx = (float)(h & 0xFFFFu) / 65536.0f;
+  *jy = (float)(h >> 16) / 65536.0f;
+}
+
 /* ---------- raytrace.comp:686-705 ---------- */
 static void renderPixel(Ctx *c, int px, int py, float *out_f32, uint8_t *out_rgba8) {
-  float uvx = (float)px / (float)c->width;
-  float uvy = (float)py / (float)c->height;
-  uvy = 1.0f - uvy;
-  Ray ray = createCameraRay(c, uvx, uvy);
-  v3 color = traceIterative(c, ray);
-  color = V3(gl_clamp(color.x, 0.0f, 1.0f), gl_clamp(color.y, 0.0f, 1.0f),
-             gl_clamp(color.z, 0.0f, 1.0f));
+  v3 color = V3(0, 0, 0);
+  int n = c->num_samples > 1 ? c->num_samples : 1;
+  v3 sum = V3(0, 0, 0);
+  for (int k = 0; k < n; k++) {
+    float jx, jy;
+    pto_sample_offset((uint32_t)py * (uint32_t)c->width + (uint32_t)px, (uint32_t)(c->first_sample + k), &jx, &jy);
+    float uvx = ((float)px + jx) / (float)c->width;
+    float uvy = ((float)py + jy) / (float)c->height;
+    uvy = 1.0f - uvy;
+    Ray ray = createCameraRay(c, uvx, uvy);
+    color = traceIterative(c, ray);
+    color = V3(gl_clamp(color.x, 0.0f, 1.0f), gl_clamp(color.y, 0.0f, 1.0f),
+               gl_clamp(color.z, 0.0f, 1.0f));
+    sum = add3(sum, color);
+  }
+  /* accumulation: running sum of the clamped samples, divided by the count */
+  if (n > 1) color = V3(sum.x / (float)n, sum.y / (float)n, sum.z / (float)n);
   size_t i = ((size_t)py * (size_t)c->width + (size_t)px) * 4;
   if (out_f32) {
     out_f32[i + 0] = color.x; out_f32[i + 1] = color.y;
@@ -666,6 +724,14 @@ int pto_render(const PtoScene *scene, const PtPushConstants *pc, int width,
                int height, int max_bounces, int row_begin, int row_end,
                float *out_f32, uint8_t *out_rgba8, uint64_t *counters,
                int nthreads) {
+  return pto_render_ex(scene, pc, width, height, max_bounces, row_begin, row_end, out_f32, out_rgba8,
+                       counters, nthreads, NULL);
+}
+
+int pto_render_ex(const PtoScene *scene, const PtPushConstants *pc, int width,
+                  int height, int max_bounces, int row_begin, int row_end,
+                  float *out_f32, uint8_t *out_rgba8, uint64_t *counters,
+                  int nthreads, const PtoOptions *opt) {
   if (nthreads < 1) nthreads = 1;
   if (row_begin < 0) row_begin = 0;
   if (row_end > height) row_end = height;
@@ -677,6 +743,9 @@ int pto_render(const PtoScene *scene, const PtPushConstants *pc, int width,
     jobs[t].ctx.width = width;
     jobs[t].ctx.height = height;
     jobs[t].ctx.max_bounces = max_bounces;
+    jobs[t].ctx.volume_filter = opt ? opt->volume_filter : 0;
+    jobs[t].ctx.first_sample = opt ? opt->first_sample : 0;
+    jobs[t].ctx.num_samples = opt ? opt->num_samples : 1;
     jobs[t].tid = t;
     jobs[t].nthreads = nthreads;
     jobs[t].row_begin = row_begin;

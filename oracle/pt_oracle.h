@@ -44,6 +44,21 @@ int pto_render(const PtoScene *scene, const PtPushConstants *pc, int width,
                float *out_f32, uint8_t *out_rgba8, uint64_t *counters,
                int nthreads);
 
+/* Extensions without a counterpart in the reference (all zero = the reference). */
+typedef struct PtoOptions {
+  int volume_filter; /* 0 nearest neighbour (raytrace.comp:485-517), 1 trilinear */
+  int first_sample;  /* index of the first sub-pixel sample; sample 0 is the reference's */
+  int num_samples;   /* > 1: the frame is the mean of the clamped samples first..first+n-1 */
+} PtoOptions;
+
+int pto_render_ex(const PtoScene *scene, const PtPushConstants *pc, int width,
+                  int height, int max_bounces, int row_begin, int row_end,
+                  float *out_f32, uint8_t *out_rgba8, uint64_t *counters,
+                  int nthreads, const PtoOptions *opt);
+
+/* Sub-pixel offset of sample s of a pixel (sample 0: none). */
+void pto_sample_offset(uint32_t pixel, uint32_t s, float *jx, float *jy);
+
 /* Single-function probes used by the known-answer tests. */
 
 /* hitSphere: returns 1 on hit and fills t, point[3], normal[3]. */

@@ -88,7 +88,14 @@ struct PtRenderer {
   bool sceneHuge = false; // a sphere with a non-finite or > 1e9 centre/radius: rays take the exact routine
   int numSpheres = 0, numEllipsoids = 0, numMaterials = 0, numLights = 0, numVolumes = 0;
   int numEmSpheres = 0, numEmEllipsoids = 0;
-  DevBuf dSpheres, dImage, dVoxels;
+  DevBuf dSpheres, dImage, dVoxels, dBricks; // dBricks: volume 0 re-tiled into 8x8x8 bricks
+  int brickRes[3] = {0, 0, 0};               // resolution dBricks was built for (0: not built)
+  bool volumeBricks = true;                  // PT_OPT_VOLUME_BRICKS
+  int volumeFilter = 0;                      // PT_OPT_VOLUME_FILTER
+  DevBuf dAccum;                             // float4 sum per pixel (pt_render_samples)
+  int accumCount = 0;                        // samples in dAccum
+  int sampleIndex = 0;                       // sample drawn by the next launch
+  bool accumulate = false;
   int imageFloat4s = 0, offEll = 0, offEllPair = 0, offMat = 0, offLight = 0, offEmS = 0, offEmE = 0, offMatIdx = 0, matIdxEllBase = 0;
   bool voxelsUploaded = false;
   size_t voxelBytes = 0;
@@ -204,6 +211,11 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   P.offMatIdx = r->offMatIdx;
   P.matIdxEllBase = r->matIdxEllBase;
   P.voxels = (const uint8_t *)r->dVoxels.p;
+  if (r->volumeBricks && pc->numVolumes > 0 && r->brickRes[0] > 0) {
+    P.voxels = (const uint8_t *)r->dBricks.p;
+    P.brickX = (r->brickRes[0] + 7) / 8;
+    P.brickY = (r->brickRes[1] + 7) / 8;
+  }
   P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8.p);
   P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr));
   P.tileCounter = (unsigned int *)((char *)r->dScratch.p + 256);
@@ -236,15 +248,23 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   else if (objBytes <= 32 * 1024) { threads = 256; blocksPerCu = 4; }   // 4 x (32 + 4) KiB
   else if (objBytes <= 64 * 1024) { threads = 512; blocksPerCu = 2; }   // 2 x (64 + 8) KiB
   else { threads = 1024; blocksPerCu = 1; }                             // 1 x (<=144 + 16) KiB
+  if ((r->tune >> 16) & 0xff) { threads = 64 * ((r->tune >> 16) & 0x1f); blocksPerCu = std::max(1, (r->tune >> 21) & 7); } // experiment: waves per group, groups per CU
   size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15); // + the kernel's copy of the frame constants
   P.sceneHuge = r->sceneHuge ? 1 : 0;
+  P.volumeFilter = r->volumeFilter;
+  P.sampleIndex = r->sampleIndex;
+  if (r->accumulate) {
+    PT_HIP_CHECK(r->dAccum.reserve((size_t)r->width * (size_t)std::max(r->localRows, 1) * sizeof(float4)));
+    P.accum = (float4 *)r->dAccum.p;
+    P.accumCount = r->accumCount + 1;
+  }
   P.tune = r->tune;
   {
     // Break-even between one dense pass (about 7.5 instructions per sphere, whatever the number
     // of rays) and the exact routine (about 0.31 per sphere + 150, per ray).
     const double ns = (double)pc->numSpheres;
     const int t = (int)(7.5 * ns / (0.31 * ns + 150.0));
-    P.sparseLanes = (r->tune >> 8) ? ((r->tune >> 8) & 0xff) - 1 : std::min(t, 32);
+    P.sparseLanes = ((r->tune >> 8) & 0xff) ? ((r->tune >> 8) & 0xff) - 1 : std::min(t, 32);
   }
   long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
@@ -320,7 +340,7 @@ void pt_destroy(PtRenderer *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch, &r->dTileOrder};
+  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch, &r->dTileOrder, &r->dBricks, &r->dAccum};
   for (DevBuf *b : bufs) b->release();
   if (r->evBegin) (void)hipEventDestroy(r->evBegin);
   if (r->evEnd) (void)hipEventDestroy(r->evEnd);
@@ -467,11 +487,32 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
       PT_HIP_CHECK(hipMemcpyAsync(r->dVoxels.p, voxels, std::min(need, voxel_bytes), hipMemcpyHostToDevice, r->stream));
       r->voxelsUploaded = true;
       r->voxelBytes = need;
+      r->brickRes[0] = 0; // rebuild the bricked copy
     } else if (!r->voxelsUploaded || r->voxelBytes < need) {
       // A volume without data marches through zeros.
       PT_HIP_CHECK(r->dVoxels.reserve(need + 16));
       PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream));
       r->voxelBytes = need;
+      r->brickRes[0] = 0;
+    }
+  }
+  if (num_volumes > 0) {
+    // Bricked copy for the march (the linear copy stays: the reference keeps the file's bytes and
+    // indexes them with whatever resolution the current scene states).
+    const PtGPUVolumetricData &v = volumes[0];
+    if (r->brickRes[0] != v.resolution_x || r->brickRes[1] != v.resolution_y || r->brickRes[2] != v.resolution_z) {
+      const int nbx = (v.resolution_x + 7) / 8, nby = (v.resolution_y + 7) / 8, nbz = (v.resolution_z + 7) / 8;
+      const long long brickBytes = (long long)nbx * nby * nbz * 512;
+      if (brickBytes <= 0x7fffffffll) { // the march indexes with 32-bit integers
+        PT_HIP_CHECK(r->dBricks.reserve((size_t)brickBytes));
+        const int grid = (int)std::min<long long>((brickBytes / 4 + 255) / 256, 65536);
+        hipLaunchKernelGGL(ptdev::pt_brick_volume_kernel, dim3(grid), dim3(256), 0, r->stream, (const uint8_t *)r->dVoxels.p,
+                           (uint8_t *)r->dBricks.p, v.resolution_x, v.resolution_y, v.resolution_z, nbx, nby, nbz);
+        PT_HIP_CHECK(hipGetLastError());
+        r->brickRes[0] = v.resolution_x; r->brickRes[1] = v.resolution_y; r->brickRes[2] = v.resolution_z;
+      } else {
+        r->brickRes[0] = r->brickRes[1] = r->brickRes[2] = 0;
+      }
     }
   }
   // The host vectors die at return: finish the copies first.
@@ -509,6 +550,22 @@ int pt_reset_voxels(PtRenderer *r) {
 }
 
 int pt_render(PtRenderer *r, const PtPushConstants *pc) { return launch_frame(r, pc, 0); }
+
+int pt_render_samples(PtRenderer *r, const PtPushConstants *pc, int first_sample, int num_samples, int keep) {
+  if (!r || !pc) return fail(PT_ERR_INVALID, "pt_render_samples: null argument");
+  if (first_sample < 0 || num_samples < 1) return fail(PT_ERR_INVALID, "pt_render_samples: first_sample >= 0 and num_samples >= 1 required");
+  if (!keep) r->accumCount = 0;
+  r->accumulate = true;
+  int rc = PT_OK;
+  for (int s = 0; s < num_samples && rc == PT_OK; ++s) {
+    r->sampleIndex = first_sample + s;
+    rc = launch_frame(r, pc, 0);
+    if (rc == PT_OK) r->accumCount++;
+  }
+  r->accumulate = false;
+  r->sampleIndex = 0;
+  return rc;
+}
 
 int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters) {
   if (!counters) return fail(PT_ERR_INVALID, "pt_render_counted: counters is null");
@@ -643,6 +700,11 @@ int pt_set_option(PtRenderer *r, int option, int value) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_option: renderer is null");
   switch (option) {
   case PT_OPT_FLOAT_OUTPUT: r->floatOutput = value != 0; return PT_OK;
+  case PT_OPT_VOLUME_BRICKS: r->volumeBricks = value != 0; return PT_OK;
+  case PT_OPT_VOLUME_FILTER:
+    if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_VOLUME_FILTER takes 0 or 1");
+    r->volumeFilter = value;
+    return PT_OK;
   case PT_OPT_TILE_ORDER:
     if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_TILE_ORDER takes 0, 1 or 2");
     r->tileOrder = value;

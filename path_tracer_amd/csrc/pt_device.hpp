@@ -73,7 +73,8 @@ struct FrameParams {
   int offEll, offEllPair, offMat, offLight, offEmS, offEmE, offMatIdx;
   int matIdxEllBase;         // element offset of the ellipsoid part of the uint16 table
   const float4 *spheres;     // (cx, cy, cz, r), one per sphere, global memory
-  const uint8_t *voxels;
+  const uint8_t *voxels;   // linear (x fastest, as uploaded) when brickX == 0, else bricked
+  int brickX, brickY;      // bricks per row and per slice of the bricked copy
   uint32_t *outRgba8;
   float4 *outF32;           // may be null
   unsigned int *tileCounter;    // kTicketGroups counters, kTicketStride apart
@@ -83,6 +84,11 @@ struct FrameParams {
   // length of list c.  Tickets run through class 2, then 1, then 0.
   int *tileOrder;
   unsigned int *classCount;
+  // Extensions without a counterpart in the reference (all zero: the reference's frame)
+  int volumeFilter; // 0 nearest neighbour (raytrace.comp:485-517), 1 trilinear
+  int sampleIndex;  // sub-pixel sample drawn by this launch; 0 = the reference's pixel-corner sample
+  int accumCount;   // with accum: number of samples in the sum after this launch
+  float4 *accum;    // running sum of the clamped samples per pixel, or null
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
   int tune; // experiment switches (bit mask), 0 in production; bit 0: no wave priorities
 };
@@ -196,8 +202,16 @@ __device__ __forceinline__ bool tile_pixel(const FrameParams &P, int tile, int w
 
 // createCameraRay for pixel (x, gy) (raytrace.comp:121-140 with main()'s uv, :692-700)
 __device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) {
-  float uvx = (float)x / (float)P.width;
-  float uvy = (float)gy / (float)P.height;
+  float fx = (float)x, fy = (float)gy;
+  if (P.sampleIndex != 0) {
+    // sub-pixel offset in [0,1)^2 from a counter-based hash of (pixel, sample)
+    uint32_t h = ((uint32_t)gy * (uint32_t)P.width + (uint32_t)x) * 0x9E3779B1u + (uint32_t)P.sampleIndex * 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    fx = fx + (float)(h & 0xFFFFu) / 65536.0f;
+    fy = fy + (float)(h >> 16) / 65536.0f;
+  }
+  float uvx = fx / (float)P.width;
+  float uvy = fy / (float)P.height;
   uvy = 1.0f - uvy;
   const float sx = ((uvx - 0.5f) * P.aspect) * P.fov;
   const float sy = (uvy - 0.5f) * P.fov;
@@ -491,7 +505,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // With only a few rays left in the wave (the end of the frame), the dense
       // loop would still cost a full pass; those rays go through the exact
       // routine instead, whose cost is per ray.
-      const bool sparse = __popcll(__ballot(live)) <= P.sparseLanes;
+      const bool sparse = (int)__popcll(__ballot(live)) <= P.sparseLanes;
       const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0 && !sparse;
       const bool special = live && !fastLane;
       // lanes whose ellipsoid roots can be deferred too: finite ray with a usable direction
@@ -934,6 +948,54 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               int stepCount = 0;
               const V3 vpos = ld3(L.volPos), lo = ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
               const uint8_t *__restrict__ vox = P.voxels;
+              const bool bricked = P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
+              const int nbx = P.brickX, nby = P.brickY;
+              if (L.volumeFilter == 1) {
+                // Trilinear extension: voxel centres at (i + 0.5) / res; lerp(a, b, t) =
+                // fma(t, b - a, a) along x, then y, then z on the byte values, then / 255.
+                const bool brk = P.brickX > 0;
+                const int bX = P.brickX, bY = P.brickY;
+                auto fetch = [&](int ix, int iy, int iz) -> float {
+                  const int id = brk ? ((((iz >> 3) * bY + (iy >> 3)) * bX + (ix >> 3)) << 9) +
+                                           (((iz & 7) << 6) | ((iy & 7) << 3) | (ix & 7))
+                                     : ix + iy * rx + iz * rx * ry;
+                  return (float)vox[id];
+                };
+                while (t < tFar && stepCount < 500) {
+                  const V3 pos = madd3(curO, t, curD);
+                  const V3 rel = sub3(pos, vpos);
+                  float density = 0.0f;
+                  if (!(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z)) {
+                    const float u[3] = {(rel.x - lo.x) / ext.x, (rel.y - lo.y) / ext.y, (rel.z - lo.z) / ext.z};
+                    const float rf[3] = {rxf, ryf, rzf};
+                    const int ri[3] = {rx, ry, rz};
+                    int i0[3], i1[3];
+                    float f[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                      const float p = u[a] * rf[a] - 0.5f;
+                      const float top = (float)(ri[a] - 1);
+                      float q = p < 0.0f ? 0.0f : (p > top ? top : p);
+                      if (q != q) q = 0.0f;
+                      i0[a] = (int)q;
+                      f[a] = q - (float)i0[a];
+                      i1[a] = i0[a] + 1 > ri[a] - 1 ? ri[a] - 1 : i0[a] + 1;
+                    }
+                    const float b000 = fetch(i0[0], i0[1], i0[2]), b100 = fetch(i1[0], i0[1], i0[2]);
+                    const float b010 = fetch(i0[0], i1[1], i0[2]), b110 = fetch(i1[0], i1[1], i0[2]);
+                    const float b001 = fetch(i0[0], i0[1], i1[2]), b101 = fetch(i1[0], i0[1], i1[2]);
+                    const float b011 = fetch(i0[0], i1[1], i1[2]), b111 = fetch(i1[0], i1[1], i1[2]);
+                    const float c00 = __builtin_fmaf(f[0], b100 - b000, b000), c10 = __builtin_fmaf(f[0], b110 - b010, b010);
+                    const float c01 = __builtin_fmaf(f[0], b101 - b001, b001), c11 = __builtin_fmaf(f[0], b111 - b011, b011);
+                    const float c0 = __builtin_fmaf(f[1], c10 - c00, c00), c1 = __builtin_fmaf(f[1], c11 - c01, c01);
+                    density = __builtin_fmaf(f[2], c1 - c0, c0) / 255.0f;
+                  }
+                  const float sampleAlpha = density * absorptionCoeff;
+                  acc = __builtin_fmaf(1.0f - acc, sampleAlpha, acc);
+                  t += 0.02f;
+                  stepCount++;
+                }
+              }
               // The march has no data-dependent exit, so four steps are taken per
               // trip: their voxel loads are in flight together and the accumulation
               // then runs in step order, exactly as one step per trip would.
@@ -961,7 +1023,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                     ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix);
                     iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
                     iz = iz < 0 ? 0 : (iz > rz - 1 ? rz - 1 : iz);
-                    index[u] = ix + iy * rx + iz * rx * ry;
+                    index[u] = bricked ? ((((iz >> 3) * nby + (iy >> 3)) * nbx + (ix >> 3)) << 9) +
+                                             (((iz & 7) << 6) | ((iy & 7) << 3) | (ix & 7))
+                                       : ix + iy * rx + iz * rx * ry;
                   }
                 }
                 unsigned int raw[4];
@@ -1188,11 +1252,19 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           break;
         }
         case GO_FINISH: { // main() :703-704
-          const float r = glclamp(fin.x, 0.0f, 1.0f), g = glclamp(fin.y, 0.0f, 1.0f), b = glclamp(fin.z, 0.0f, 1.0f);
-          if (!(P.tune & 4)) {
+          float r = glclamp(fin.x, 0.0f, 1.0f), g = glclamp(fin.y, 0.0f, 1.0f), b = glclamp(fin.z, 0.0f, 1.0f);
+          if (P.accum) { // mean of the clamped samples so far
+            float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (L.accumCount > 1) sum = P.accum[outIdx];
+            sum = make_float4(sum.x + r, sum.y + g, sum.z + b, 0.0f);
+            P.accum[outIdx] = sum;
+            if (L.accumCount > 1) {
+              const float n = (float)L.accumCount;
+              r = sum.x / n; g = sum.y / n; b = sum.z / n;
+            }
+          }
           P.outRgba8[outIdx] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
           if (P.outF32) P.outF32[outIdx] = make_float4(r, g, b, 1.0f);
-          }
           state = ST_IDLE;
           step = GO_EMITTED;
           break;
@@ -1255,6 +1327,26 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 // De-interleave the compact band-major frames of `bandCount` renderers into
 // one height x width frame.  Source frame of renderer p starts at
 // p * strideRows rows; elements are uint32 (rgba8) or float4.
+// Re-tile a linear x-fastest volume into 8x8x8 bricks (512 contiguous bytes
+// each; bricks x fastest).  Voxels outside the volume are written as 0.
+__global__ void __launch_bounds__(256) pt_brick_volume_kernel(const uint8_t *__restrict__ linear, uint8_t *__restrict__ bricks,
+                                                              int rx, int ry, int rz, int nbx, int nby, int nbz) {
+  const long long total = (long long)nbx * nby * nbz * 128; // 4 voxels per thread
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long brick = i >> 7;
+    const int in = (int)(i & 127) << 2; // first of 4 voxels along x
+    const int bx = (int)(brick % nbx), by = (int)((brick / nbx) % nby), bz = (int)(brick / ((long long)nbx * nby));
+    const int ix = (bx << 3) | (in & 7), iy = (by << 3) | ((in >> 3) & 7), iz = (bz << 3) | (in >> 6);
+    uint32_t w = 0;
+    if (iy < ry && iz < rz) {
+      const long long base = ix + (long long)iy * rx + (long long)iz * rx * ry;
+      for (int k = 0; k < 4; ++k)
+        if (ix + k < rx) w |= (uint32_t)linear[base + k] << (8 * k);
+    }
+    ((uint32_t *)bricks)[i] = w;
+  }
+}
+
 template <typename T>
 __global__ void pt_assemble_bands_kernel(const T *__restrict__ src, T *__restrict__ dst, int width, int height,
                                          int bandRows, int bandCount, int strideRows) {

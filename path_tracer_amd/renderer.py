@@ -119,6 +119,12 @@ class HipRenderer:
         _lib.check(self._lib.pt_render_counted(self._h, pc.ctypes.data, cnt.ctypes.data))
         return cnt
 
+    def renderSamples(self, pushConstants, first_sample: int = 0, num_samples: int = 1, keep: bool = False) -> None:
+        """Mean of sub-pixel samples first_sample .. first_sample + num_samples - 1 (sample 0 is the
+        reference's pixel-corner sample); keep=True continues the previous call's sum."""
+        pc = self._pc(pushConstants)
+        _lib.check(self._lib.pt_render_samples(self._h, pc.ctypes.data, first_sample, num_samples, 1 if keep else 0))
+
     def setRowBands(self, band_rows: int, band_index: int, band_count: int) -> None:
         _lib.check(self._lib.pt_set_row_bands(self._h, band_rows, band_index, band_count))
 

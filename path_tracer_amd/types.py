@@ -104,3 +104,11 @@ N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 # sorted paths get 1, 2, ...; 0 is the built-in Phong).
 SHADER_RAINBOW = "shaders/surface_shaders/rainbow.glsl"
 SHADER_TOON = "shaders/surface_shaders/toon.glsl"
+
+
+# pt_set_option keys (include/pt_hip.h)
+OPT_FLOAT_OUTPUT = 1
+OPT_OBJECT_SOURCE = 2
+OPT_TILE_ORDER = 3
+OPT_VOLUME_BRICKS = 4
+OPT_VOLUME_FILTER = 5

@@ -296,3 +296,26 @@ def test_unknown_shader_index_returns_black(oracle):
     sc.materials = np.array([g], dtype=T.GPU_MATERIAL)
     _, f32, _ = oracle.render(sc, nthreads=1)
     np.testing.assert_array_equal(f32[24, 32, :3], 0.0)
+
+
+def test_oracle_sample_offsets_are_in_the_pixel(oracle):
+    for pixel in (0, 1, 12345, 2 ** 31 + 7):
+        assert oracle.sample_offset(pixel, 0) == (0.0, 0.0)
+        for s in range(1, 64):
+            jx, jy = oracle.sample_offset(pixel, s)
+            assert 0.0 <= jx < 1.0 and 0.0 <= jy < 1.0
+
+
+def test_oracle_extensions_default_to_the_reference(oracle):
+    """One sample / nearest filter through the extended entry point is the plain frame; the
+    trilinear filter on a constant volume changes nothing (every lerp of equal values)."""
+    res = (12, 10, 9)
+    vox = np.full(res[0] * res[1] * res[2], 40, dtype=np.uint8)
+    sc = scenes.config4(96, 54, voxels=vox, resolution=res)
+    a8, af, ac = oracle.render(sc, nthreads=2)
+    b8, bf, bc = oracle.render(sc, nthreads=2, volume_filter=0, first_sample=0, num_samples=1)
+    np.testing.assert_array_equal(af.view(np.uint32), bf.view(np.uint32))
+    t8, tf, tc = oracle.render(sc, nthreads=2, volume_filter=1)
+    np.testing.assert_array_equal(af.view(np.uint32), tf.view(np.uint32))
+    m8, mf, mc = oracle.render(sc, nthreads=2, num_samples=3)
+    assert int(mc[0]) == 3 * int(ac[0])  # three samples, three times the rays
