@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 import pmc_summary  # noqa: E402
 
 
-def kernel_counter(db, counter, kernel_like="pt_render_kernel<false"):
+def kernel_counter(db, counter, kernel_like="pt_render_kernel<0,"):
     con = sqlite3.connect(db)
     acc, disp = 0.0, set()
     for k, did, cname, val in con.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
@@ -46,8 +46,8 @@ def main():
         pmc_summary.main()
     with open(os.path.join(out, f"{rnd}_kernel_trace.txt"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras\n")
-        f.write("# (default workload c2: 12 launches of pt_render_kernel<false,...> = 2 warm-up + 10 timed; <true,...> is the\n")
-        f.write("#  instrumented, untimed counting launch)\n")
+        f.write("# (default workload c2: 12 launches of pt_render_kernel<0,...> = 2 warm-up + 10 timed; <1,...> and <2,...> are the\n")
+        f.write("#  instrumented, untimed counting and phase-timing launches)\n")
         f.write(buf.getvalue())
         for wl in ("c3", "c4"):
             d = os.path.join(src, f"trace_{wl}")
@@ -68,7 +68,7 @@ def main():
                      if "rocclr" not in l and not (l.startswith("   ") and float(l.split()[-1]) < 1e4))
     with open(os.path.join(out, f"{rnd}_pmc.txt"), "w") as f:
         f.write("# one rocprofv3 --pmc pass per block; bench.py --workload <wl> --steps 3 --warmup 1 --no-extras --no-cpu\n")
-        f.write("# FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; <true,...> is the instrumented (untimed) launch\n")
+        f.write("# FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; <1,...> and <2,...> are the instrumented (untimed) launch\n")
         f.write(text + "\n")
     traffic = {}
     for wl in ("c2", "c3", "c4"):
