@@ -129,6 +129,9 @@ enum {
   PT_CNT_CYC_ELLIPSOIDS,  /* device only: wave-cycles in the ellipsoid loop                   */
   PT_CNT_CYC_SHADE,       /* device only: wave-cycles consuming results / shading / marching  */
   PT_CNT_CYC_EXACT,       /* device only: wave-cycles in the exact sphere routine             */
+  PT_CNT_CYC_POOLED,      /* device only: wave-cycles from joining the pooled end-of-frame mode to exit */
+  PT_CNT_POOLED_PASSES,   /* device only: passes made in pooled mode, summed over workgroups   */
+  PT_CNT_POOLED_RAYS,     /* device only: rays traced through the pooled list                  */
   PT_CNT_COUNT
 };
 

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
-N_COUNTERS = 18
+N_COUNTERS = 21
 
 
 class _PtoScene(C.Structure):

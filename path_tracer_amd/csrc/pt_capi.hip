@@ -121,8 +121,8 @@ struct PtRenderer {
 
 namespace {
 
-// dScratch: class counts (3 x 4 B) at +16, counters (PT_CNT_COUNT x 8 B) at +64, tile-ticket counters at +256
-constexpr size_t kScratchBytes = 256 + (size_t)ptdev::kTicketGroups * ptdev::kTicketStride * sizeof(unsigned int);
+// dScratch: class counts (3 x 4 B) at +16, counters (PT_CNT_COUNT x 8 B) at +64, tile-ticket counters at +512
+constexpr size_t kScratchBytes = 512 + (size_t)ptdev::kTicketGroups * ptdev::kTicketStride * sizeof(unsigned int);
 
 int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {
   if (bandCount <= 1) return height;
@@ -218,7 +218,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   }
   P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8.p);
   P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr));
-  P.tileCounter = (unsigned int *)((char *)r->dScratch.p + 256);
+  P.tileCounter = (unsigned int *)((char *)r->dScratch.p + 512);
   P.counters = (unsigned long long *)((char *)r->dScratch.p + 64);
 
   if (P.numTiles <= 0) return PT_OK;
@@ -250,6 +250,14 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   else { threads = 1024; blocksPerCu = 1; }                             // 1 x (<=144 + 16) KiB
   if ((r->tune >> 16) & 0xff) { threads = 64 * ((r->tune >> 16) & 0x1f); blocksPerCu = std::max(1, (r->tune >> 21) & 7); } // experiment: waves per group, groups per CU
   size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15); // + the kernel's copy of the frame constants
+  // Pooled tracing at the end of the frame pays when one pass over the spheres is long.
+  {
+    const size_t coopBytes = 64 + (size_t)threads * (6 * sizeof(float) + sizeof(unsigned long long)) +
+                             (size_t)(threads / 4) * (7 * sizeof(float) + sizeof(unsigned long long)); // pooled rays + exact-routine rays
+    const bool fits = ldsBytes + coopBytes <= 160 * 1024 / (size_t)blocksPerCu;
+    P.coop = (pc->numSpheres >= 256 && fits && !(r->tune & 16)) ? 1 : 0;
+    if (P.coop) ldsBytes += coopBytes;
+  }
   P.sceneHuge = r->sceneHuge ? 1 : 0;
   P.volumeFilter = r->volumeFilter;
   P.sampleIndex = r->sampleIndex;

@@ -89,6 +89,7 @@ struct FrameParams {
   int sampleIndex;  // sub-pixel sample drawn by this launch; 0 = the reference's pixel-corner sample
   int accumCount;   // with accum: number of samples in the sum after this launch
   float4 *accum;    // running sum of the clamped samples per pixel, or null
+  int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
   int tune; // experiment switches (bit mask), 0 in production; bit 0: no wave priorities
 };
@@ -345,6 +346,19 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     __syncthreads();
   }
   const FrameParams &L = *paramsLds;
+  // Pooled tracing at the end of the frame (P.coop): control words, the pooled
+  // rays (six arrays of blockDim.x floats) and one result slot per pooled ray.
+  const int nThreads = (int)blockDim.x, nWaves = (int)(blockDim.x >> 6), waveInBlock = (int)(threadIdx.x >> 6);
+  char *const coopBase = (char *)paramsLds + ((sizeof(FrameParams) + 15) & ~(size_t)15);
+  volatile int *const c_ctrl = (volatile int *)coopBase; // [0] switch, [1..2] pooled-ray count, [3..4] any ray left (by parity)
+  float *const c_rays = (float *)(coopBase + 64);
+  unsigned long long *const c_slot = (unsigned long long *)(coopBase + 64 + 6 * sizeof(float) * (size_t)nThreads);
+  if (P.coop) {
+    if (threadIdx.x < 8) c_ctrl[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  bool coop = false; // wave-uniform: this wave has joined the pooled mode
+  int coopPass = 0;
   const int lane = threadIdx.x & 63;
   const unsigned long long laneMaskLt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   // per-wave scratch behind the object image: 128-entry candidate ring + 64 result slots (1 KiB)
@@ -385,6 +399,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
   unsigned int cGroups = 0, cSlow = 0;  // wave-level: 4-sphere trips, trips that left the fast path
   unsigned int cExact = 0;              // rays this lane sent to the exact routine
+  unsigned long long tPooled = 0, nPooled = 0, nPooledRays = 0;
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
 #define PT_PHASE(ACC) if (PHASES) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
   if (PHASES) tPhase = __builtin_amdgcn_s_memtime();
@@ -462,7 +477,16 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         poolNext += nIdle;
       }
     }
-    if (__ballot(state != ST_IDLE) == 0ull) break;
+    if (P.coop && !coop) {
+      // The first wave of the workgroup that finds every ticket group drained asks
+      // all of them to switch; each joins at the top of its next pass.
+      if (exhausted && lane == 0) c_ctrl[0] = 1;
+      if (__builtin_amdgcn_readfirstlane(c_ctrl[0]) != 0) {
+        coop = true;
+        if (PHASES) tPooled = __builtin_amdgcn_s_memtime();
+      }
+    }
+    if (!coop && __ballot(state != ST_IDLE) == 0ull) break;
     // Waves that carry bounced paths, or that are finishing their last pixels,
     // hold the longest chains of dependent rays: let them issue first.
     if (!(P.tune & 1)) {
@@ -505,67 +529,65 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // With only a few rays left in the wave (the end of the frame), the dense
       // loop would still cost a full pass; those rays go through the exact
       // routine instead, whose cost is per ray.
-      const bool sparse = (int)__popcll(__ballot(live)) <= P.sparseLanes;
+      const bool sparse = !coop && (int)__popcll(__ballot(live)) <= P.sparseLanes;
       const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0 && !sparse;
       const bool special = live && !fastLane;
       // lanes whose ellipsoid roots can be deferred too: finite ray with a usable direction
       const bool qLane = live && finiteRay && P.sceneHuge == 0 && dLen2 >= 1.0e-30f;
       if (COUNT && live) cRays++;
       if (COUNT && special) cExact++;
-      // lanes without a finite ray get one that can never produce a candidate
-      const float ox = fastLane ? rO.x : 4.0e9f, oy = fastLane ? rO.y : 4.0e9f, oz = fastLane ? rO.z : 4.0e9f;
-      const float dx = fastLane ? rD.x : 0.0f, dy = fastLane ? rD.y : 0.0f, dz = fastLane ? rD.z : 0.0f;
-
-      // slot[lane] = (bits(t) << 32) | ~(index + 1) of the best accepted sphere so
+      // slot[lane] = (bits(t) << 32) | ~(index + 1) of the best accepted object so
       // far; t >= tMin > 0, so unsigned order on the bits is float order, and on
       // equal t the larger index has the smaller key.  Start at (tMax, none):
       // acceptance is t <= tMax.
-      {
-        unsigned long long init = 0ull; // tMax < tMin: nothing can be accepted
-        if (rTmax >= tMin) init = ((unsigned long long)__float_as_uint(rTmax) << 32) | 0xFFFFFFFFull;
-        w_slot[lane] = init;
-      }
-      int qHead = 0, qTail = 0; // ring of 128 entries, wave-uniform cursors
+      unsigned long long slotInit = 0ull; // tMax < tMin: nothing can be accepted
+      if (rTmax >= tMin) slotInit = ((unsigned long long)__float_as_uint(rTmax) << 32) | 0xFFFFFFFFull;
+      w_slot[lane] = slotInit;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-      // Evaluate n <= 64 queued (lane, sphere) candidates, one per lane.
-      auto drain = [&](int n) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned int e = w_queue[(qHead + lane) & 127];
-        const bool on = lane < n;
-        const int owner = on ? (int)(e & 63u) : lane;
-        const int idx = on ? (int)(e >> 6) : 0;
-        const float eox = __shfl(ox, owner), eoy = __shfl(oy, owner), eoz = __shfl(oz, owner);
-        const float edx = __shfl(dx, owner), edy = __shfl(dy, owner), edz = __shfl(dz, owner);
-        float cx, cy, cz, rr;
-        if (LDS_OBJECTS) { // the pair image starts at float4 0 of the scene image
-          const float *sf = (const float *)s_obj;
-          const int f = 8 * (idx >> 1) + (idx & 1);
-          cx = sf[f]; cy = sf[f + 2]; cz = sf[f + 4]; rr = sf[f + 6];
-        } else {
-          const float4 sp = P.spheres[idx];
-          cx = sp.x; cy = sp.y; cz = sp.z; rr = sp.w;
-        }
-        // hitSphere (raytrace.comp:142-159), same operations as the packed loop
-        const float ocx = eox - cx, ocy = eoy - cy, ocz = eoz - cz;
-        const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
-        const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
-        const float cc = __builtin_fmaf(-rr, rr, dd);
-        const float disc = __builtin_fmaf(hb, hb, -cc);
-        const float sq = __builtin_sqrtf(disc);
-        float t = -hb - sq;
-        if (t < tMin) t = -hb + sq;
-        // accepted iff tMin <= t <= closest-so-far; the atomic min applies the upper bound
-        if (on && !(t < tMin)) {
-          const unsigned long long key =
-              ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(~((unsigned int)idx + 1u));
-          atomicMin(&w_slot[owner], key);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      };
-
-      const f2 OX = mk2(ox, ox), OY = mk2(oy, oy), OZ = mk2(oz, oz);
-      const f2 DX = mk2(dx, dx), DY = mk2(dy, dy), DZ = mk2(dz, dz);
+      // The dense sphere pass for the 64 rays (ox..dz, one per lane) over sphere
+      // groups [gBegin, gEnd), results into slot[lane].  A lane without a ray
+      // passes one that can never produce a candidate (origin 4e9, direction 0).
+      auto denseSpheres = [&](const float ox, const float oy, const float oz, const float dx, const float dy,
+                              const float dz, unsigned long long *slot, const int gBegin, const int gEnd) {
+        int qHead = 0, qTail = 0; // ring of 128 entries, wave-uniform cursors
+        // Evaluate n <= 64 queued (lane, sphere) candidates, one per lane.
+        auto drain = [&](int n) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const unsigned int e = w_queue[(qHead + lane) & 127];
+          const bool on = lane < n;
+          const int owner = on ? (int)(e & 63u) : lane;
+          const int idx = on ? (int)(e >> 6) : 0;
+          const float eox = __shfl(ox, owner), eoy = __shfl(oy, owner), eoz = __shfl(oz, owner);
+          const float edx = __shfl(dx, owner), edy = __shfl(dy, owner), edz = __shfl(dz, owner);
+          float cx, cy, cz, rr;
+          if (LDS_OBJECTS) { // the pair image starts at float4 0 of the scene image
+            const float *sf = (const float *)s_obj;
+            const int f = 8 * (idx >> 1) + (idx & 1);
+            cx = sf[f]; cy = sf[f + 2]; cz = sf[f + 4]; rr = sf[f + 6];
+          } else {
+            const float4 sp = P.spheres[idx];
+            cx = sp.x; cy = sp.y; cz = sp.z; rr = sp.w;
+          }
+          // hitSphere (raytrace.comp:142-159), same operations as the packed loop
+          const float ocx = eox - cx, ocy = eoy - cy, ocz = eoz - cz;
+          const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
+          const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+          const float cc = __builtin_fmaf(-rr, rr, dd);
+          const float disc = __builtin_fmaf(hb, hb, -cc);
+          const float sq = __builtin_sqrtf(disc);
+          float t = -hb - sq;
+          if (t < tMin) t = -hb + sq;
+          // accepted iff tMin <= t <= closest-so-far; the atomic min applies the upper bound
+          if (on && !(t < tMin)) {
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(~((unsigned int)idx + 1u));
+            atomicMin(&slot[owner], key);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        };
+        const f2 OX = mk2(ox, ox), OY = mk2(oy, oy), OZ = mk2(oz, oz);
+        const f2 DX = mk2(dx, dx), DY = mk2(dy, dy), DZ = mk2(dz, dz);
 #define PT_PAIR_DISC(A, B, DISC)                                                 \
   {                                                                              \
     const f2 ocx = OX - mk2(A.x, A.y), ocy = OY - mk2(A.z, A.w), ocz = OZ - mk2(B.x, B.y); \
@@ -589,8 +611,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       if (qTail - qHead >= 64) { drain(64); qHead += 64; }                       \
     }                                                                            \
   }
-      if (__ballot(fastLane) != 0ull) {
-        for (int g = 0; g < nGroups; ++g) {
+        for (int g = gBegin; g < gEnd; ++g) {
           const float4 a0 = PT_PAIR(8 * g), b0 = PT_PAIR(8 * g + 1), a1 = PT_PAIR(8 * g + 2), b1 = PT_PAIR(8 * g + 3);
           const float4 a2 = PT_PAIR(8 * g + 4), b2 = PT_PAIR(8 * g + 5), a3 = PT_PAIR(8 * g + 6), b3 = PT_PAIR(8 * g + 7);
           f2 d0, d1, d2, d3;
@@ -614,7 +635,151 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             PT_ENQUEUE(8 * g + 7, d3.y)
           }
         }
-        if (qTail > qHead) { drain(qTail - qHead); qHead = qTail; }
+        if (qTail > qHead) drain(qTail - qHead);
+      };
+
+      // Exact routine, finite case: one ray against every sphere, one sphere per
+      // lane per chunk of 64 (coalesced 16-byte loads from the plain array).  A
+      // finite ray in a finite scene cannot produce a NaN, so the result is the
+      // smallest root >= tMin (later sphere on a tie) if it is <= tMax: each lane
+      // keeps the best of its own spheres and one reduction picks the winner.
+      // Returns the slot key of the winner, or all ones for none.
+      auto exactFinite = [&](const float eox, const float eoy, const float eoz, const float edx, const float edy,
+                             const float edz, const float etmax, unsigned int &roots) -> unsigned long long {
+        float myBest = __builtin_inff();
+        int myIdx = -1;
+        // four chunks per trip: the loads go out together and the four root
+        // chains are independent, which hides their latency
+        for (int base = 0; base < Ns; base += 256) {
+          float4 sp4[4];
+          bool in4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = base + 64 * u + lane;
+            in4[u] = j < Ns;
+            sp4[u] = P.spheres[in4[u] ? j : 0];
+          }
+          float hb4[4], disc4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float ocx = eox - sp4[u].x, ocy = eoy - sp4[u].y, ocz = eoz - sp4[u].z;
+            hb4[u] = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
+            const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+            const float cc = __builtin_fmaf(-sp4[u].w, sp4[u].w, dd);
+            disc4[u] = __builtin_fmaf(hb4[u], hb4[u], -cc);
+          }
+          float sq4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sq4[u] = __builtin_sqrtf(disc4[u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool root = in4[u] && !(disc4[u] < 0.0f);
+            const float t0 = -hb4[u] - sq4[u], t1 = -hb4[u] + sq4[u];
+            const float v = (t0 < tMin) ? t1 : t0;
+            if (root && !(v < tMin) && v <= myBest) { myBest = v; myIdx = base + 64 * u + lane; }
+            if (COUNT) roots += root ? 1u : 0u;
+          }
+        }
+        unsigned long long key = ((unsigned long long)__float_as_uint(myBest) << 32) |
+                                 (unsigned long long)(~((unsigned int)myIdx + 1u));
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned long long other = __shfl_xor(key, off, 64);
+          key = other < key ? other : key;
+        }
+        if (COUNT) for (int off = 32; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
+        const float mn = __uint_as_float((unsigned int)(key >> 32));
+        const unsigned int widx = ~(unsigned int)key - 1u;
+        return (widx < (unsigned int)Ns && !(mn > etmax)) ? key : ~0ull;
+      };
+
+      bool pooledX = false; // this lane's exact-routine ray is in the workgroup's list
+      int myXPos = 0;
+      if (coop) {
+        // Pooled pass.  Every wave of the workgroup appends its fast-path rays to
+        // one list; the list is cut into batches of 64 and each batch into as
+        // many sphere ranges as there are waves to go round, so a pass costs in
+        // proportion to the rays that are left instead of one full sphere loop
+        // per wave that still holds a ray.
+        const int par = coopPass & 1;
+        ++coopPass;
+        if (PHASES && waveInBlock == 0) nPooled++;
+        if (__ballot(live) != 0ull && lane == 0) c_ctrl[3 + par] = 1;
+        const unsigned long long fm = __ballot(fastLane);
+        int base = 0;
+        if (fm != 0ull) {
+          if (lane == 0) base = atomicAdd((int *)&c_ctrl[1 + par], (int)__popcll(fm));
+          base = __builtin_amdgcn_readfirstlane(base);
+        }
+        const int myPos = base + (int)__popcll(fm & laneMaskLt);
+        if (fastLane) {
+          c_rays[myPos] = rO.x; c_rays[nThreads + myPos] = rO.y; c_rays[2 * nThreads + myPos] = rO.z;
+          c_rays[3 * nThreads + myPos] = rD.x; c_rays[4 * nThreads + myPos] = rD.y; c_rays[5 * nThreads + myPos] = rD.z;
+          c_slot[myPos] = slotInit;
+        }
+        // finite rays for the exact routine go to a second list (up to nThreads / 4 of them)
+        const int xCap = nThreads >> 2;
+        float *const c_xrays = (float *)(c_slot + nThreads);
+        unsigned long long *const c_xslot = (unsigned long long *)(c_xrays + 7 * xCap);
+        {
+          const bool want = special && qLane;
+          const unsigned long long xm = __ballot(want);
+          int xb = 0;
+          if (xm != 0ull) {
+            if (lane == 0) xb = atomicAdd((int *)&c_ctrl[5 + par], (int)__popcll(xm));
+            xb = __builtin_amdgcn_readfirstlane(xb);
+          }
+          myXPos = xb + (int)__popcll(xm & laneMaskLt);
+          pooledX = want && myXPos < xCap;
+          if (pooledX) {
+            c_xrays[myXPos] = rO.x; c_xrays[xCap + myXPos] = rO.y; c_xrays[2 * xCap + myXPos] = rO.z;
+            c_xrays[3 * xCap + myXPos] = rD.x; c_xrays[4 * xCap + myXPos] = rD.y; c_xrays[5 * xCap + myXPos] = rD.z;
+            c_xrays[6 * xCap + myXPos] = rTmax;
+          }
+        }
+        __syncthreads();
+        if (c_ctrl[3 + par] == 0) break; // no wave of the workgroup holds a ray: all leave together
+        if (threadIdx.x == 0) { c_ctrl[1 + (par ^ 1)] = 0; c_ctrl[3 + (par ^ 1)] = 0; c_ctrl[5 + (par ^ 1)] = 0; }
+        const int pooled = __builtin_amdgcn_readfirstlane(c_ctrl[1 + par]);
+        const int batches = (pooled + 63) >> 6;
+        if (PHASES && waveInBlock == 0) nPooledRays += (unsigned long long)pooled;
+        if (batches > 0) {
+          const int split = nWaves / batches > 0 ? nWaves / batches : 1;
+          const int units = batches * split;
+          for (int u = waveInBlock; u < units; u += nWaves) {
+            const int b = u / split, part = u - b * split;
+            const int at = b * 64 + lane;
+            const bool has = at < pooled;
+            const float ox = has ? c_rays[at] : 4.0e9f, oy = has ? c_rays[nThreads + at] : 4.0e9f;
+            const float oz = has ? c_rays[2 * nThreads + at] : 4.0e9f, dx = has ? c_rays[3 * nThreads + at] : 0.0f;
+            const float dy = has ? c_rays[4 * nThreads + at] : 0.0f, dz = has ? c_rays[5 * nThreads + at] : 0.0f;
+            denseSpheres(ox, oy, oz, dx, dy, dz, c_slot + b * 64, (int)((long long)part * nGroups / split),
+                         (int)((long long)(part + 1) * nGroups / split));
+          }
+        }
+        {
+          int xCount = __builtin_amdgcn_readfirstlane(c_ctrl[5 + par]);
+          if (xCount > xCap) xCount = xCap;
+          for (int e = waveInBlock; e < xCount; e += nWaves) {
+            unsigned int roots = 0;
+            const unsigned long long key =
+                exactFinite(c_xrays[e], c_xrays[xCap + e], c_xrays[2 * xCap + e], c_xrays[3 * xCap + e],
+                            c_xrays[4 * xCap + e], c_xrays[5 * xCap + e], c_xrays[6 * xCap + e], roots);
+            if (lane == 0) {
+              c_xslot[e] = key;
+              if (COUNT) cRoots += roots;
+            }
+          }
+        }
+        __syncthreads();
+        if (fastLane) w_slot[lane] = c_slot[myPos];
+        if (pooledX) {
+          const unsigned long long key = c_xslot[myXPos];
+          if (key != ~0ull) w_slot[lane] = key;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      } else if (__ballot(fastLane) != 0ull) {
+        denseSpheres(fastLane ? rO.x : 4.0e9f, fastLane ? rO.y : 4.0e9f, fastLane ? rO.z : 4.0e9f,
+                     fastLane ? rD.x : 0.0f, fastLane ? rD.y : 0.0f, fastLane ? rD.z : 0.0f, w_slot, 0, nGroups);
       }
 
       // Exact routine for the few rays the fast path must not (non-finite) or
@@ -623,7 +788,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // behaviour: a NaN t is accepted and then voids the upper bound for the
       // next sphere) is reproduced chunk by chunk.
       PT_PHASE(cycSpheres)
-      unsigned long long todo = __ballot(special);
+      unsigned long long todo = __ballot(special && !pooledX);
       const unsigned long long finiteMask = (P.sceneHuge == 0) ? __ballot(finiteRay) : 0ull;
       while (todo != 0ull) {
         const int owner = (int)__builtin_ctzll(todo);
@@ -634,71 +799,28 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         float C = etmax; // closestT
         int win = -1;
         unsigned int roots = 0;
-#define PT_EXACT_SPHERE(J, INB)                                                   \
-          /* one sphere per lane: coalesced 16-byte loads from the plain array  \
-             (the LDS pair image would be read with a 4-way bank conflict) */     \
-          const float4 sp = P.spheres[(INB) ? (J) : 0];                           \
-          const float ocx = eox - sp.x, ocy = eoy - sp.y, ocz = eoz - sp.z;       \
-          const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx)); \
-          const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)); \
-          const float cc = __builtin_fmaf(-sp.w, sp.w, dd);                       \
-          const float disc = __builtin_fmaf(hb, hb, -cc);                         \
-          const bool root = (INB) && !(disc < 0.0f);                              \
-          const float sq = __builtin_sqrtf(disc);                                 \
-          const float t0 = -hb - sq, t1 = -hb + sq;
         if ((finiteMask >> owner) & 1ull) {
-          // Finite ray, finite scene: no NaN can appear, the result is the
-          // smallest root >= tMin (later sphere on a tie) if it is <= tMax.
-          // Each lane keeps the best of its own spheres; one reduction at the end.
-          float myBest = __builtin_inff();
-          int myIdx = -1;
-          // four chunks per trip: the loads go out together and the four root
-          // chains are independent, which hides their latency
-          for (int base = 0; base < Ns; base += 256) {
-            float4 sp4[4];
-            bool in4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int j = base + 64 * u + lane;
-              in4[u] = j < Ns;
-              sp4[u] = P.spheres[in4[u] ? j : 0];
-            }
-            float hb4[4], disc4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const float ocx = eox - sp4[u].x, ocy = eoy - sp4[u].y, ocz = eoz - sp4[u].z;
-              hb4[u] = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
-              const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
-              const float cc = __builtin_fmaf(-sp4[u].w, sp4[u].w, dd);
-              disc4[u] = __builtin_fmaf(hb4[u], hb4[u], -cc);
-            }
-            float sq4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sq4[u] = __builtin_sqrtf(disc4[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const bool root = in4[u] && !(disc4[u] < 0.0f);
-              const float t0 = -hb4[u] - sq4[u], t1 = -hb4[u] + sq4[u];
-              const float v = (t0 < tMin) ? t1 : t0;
-              if (root && !(v < tMin) && v <= myBest) { myBest = v; myIdx = base + 64 * u + lane; }
-              if (COUNT) roots += root ? 1u : 0u;
-            }
+          const unsigned long long key = exactFinite(eox, eoy, eoz, edx, edy, edz, etmax, roots);
+          if (key != ~0ull) {
+            C = __uint_as_float((unsigned int)(key >> 32));
+            win = (int)(~(unsigned int)key - 1u);
           }
-          unsigned long long key = ((unsigned long long)__float_as_uint(myBest) << 32) |
-                                   (unsigned long long)(~((unsigned int)myIdx + 1u));
-          for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long other = __shfl_xor(key, off, 64);
-            key = other < key ? other : key;
-          }
-          const float mn = __uint_as_float((unsigned int)(key >> 32));
-          const unsigned int widx = ~(unsigned int)key - 1u;
-          if (widx < (unsigned int)Ns && !(mn > C)) { C = mn; win = (int)widx; }
-          if (COUNT) for (int off = 32; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
         } else {
+          // The shader's sequential acceptance, NaN behaviour included (a NaN t is
+          // accepted and then voids the upper bound for the next sphere),
+          // reproduced chunk by chunk.
           for (int base = 0; base < Ns; base += 64) {
             const int j = base + lane;
             const bool inb = j < Ns;
-            PT_EXACT_SPHERE(j, inb)
+            const float4 sp = P.spheres[inb ? j : 0];
+            const float ocx = eox - sp.x, ocy = eoy - sp.y, ocz = eoz - sp.z;
+            const float hb = __builtin_fmaf(ocz, edz, __builtin_fmaf(ocy, edy, ocx * edx));
+            const float dd = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+            const float cc = __builtin_fmaf(-sp.w, sp.w, dd);
+            const float disc = __builtin_fmaf(hb, hb, -cc);
+            const bool root = inb && !(disc < 0.0f);
+            const float sq = __builtin_sqrtf(disc);
+            const float t0 = -hb - sq, t1 = -hb + sq;
             // a NaN root passes both range tests of hitSphere whatever closestT is
             const bool nanacc = root && ((t0 != t0) || ((t0 < tMin) && (t1 != t1)));
             float v = t0;
@@ -723,7 +845,6 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             }
           }
         }
-#undef PT_EXACT_SPHERE
         if (lane == owner) {
           if (qLane) { // finite: C is a plain t >= tMin; the ellipsoid queue continues from it
             if (win >= 0)
@@ -741,6 +862,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // Same scheme as the spheres: the wave-uniform loop computes every lane's
       // discriminant, roots go through the queue and are evaluated 64 at a time.
       // (a = |dirScaled|^2 is part of the test, so non-unit directions are fine.)
+      int qHead = 0, qTail = 0; // the candidate ring is empty again
       auto drainE = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned int e = w_queue[(qHead + lane) & 127];
@@ -1280,6 +1402,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #undef PT_PHASE
 
   if (PHASES && lane == 0) {
+    if (coop) atomicAdd(&P.counters[18], __builtin_amdgcn_s_memtime() - tPooled);
+    atomicAdd(&P.counters[19], nPooled);
+    atomicAdd(&P.counters[20], nPooledRays);
     atomicAdd(&P.counters[13], cycRefill);
     atomicAdd(&P.counters[14], cycSpheres);
     atomicAdd(&P.counters[15], cycEll);

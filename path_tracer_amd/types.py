@@ -96,6 +96,9 @@ COUNTER_NAMES = (
     "cyc_ellipsoids",
     "cyc_shade",
     "cyc_exact",
+    "cyc_pooled",       # wave-cycles between joining the pooled end-of-frame mode and exit
+    "pooled_passes",    # passes in pooled mode, summed over workgroups
+    "pooled_rays",      # rays traced through the pooled list
 )
 N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 

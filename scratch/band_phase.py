@@ -21,4 +21,4 @@ print(name,'world',world,'ms %.3f'%ms,'rays %.2fM'%(d['rays']/1e6),'waves',waves
       'trips/wave %.0f'%(d['wave_trips']/waves), 'lane util %.3f'%((d['rays']/64*((len(sc.spheres)+7)//8))/max(d['wave_trips'],1)),
       'exact rays %d'%d['exact_rays'],
       'alive frac @2.1GHz %.2f'%(tot/waves/(ms*1e-3*2.1e9)),
-      'phase: refill %.3f spheres %.3f ell %.3f shade %.3f exact %.3f'%tuple(int(cnt[i])/tot for i in range(13,18)))
+      'phase: refill %.3f spheres %.3f ell %.3f shade %.3f exact %.3f'%tuple(int(cnt[i])/tot for i in range(13,18)), 'pooled share of wave time %.3f'%(int(cnt[18])/tot), 'pooled passes per WG %.1f'%(int(cnt[19])/blocks), 'pooled rays per WG-pass %.0f'%(int(cnt[20])/max(int(cnt[19]),1)), 'pooled rays total %.2fM'%(int(cnt[20])/1e6))
