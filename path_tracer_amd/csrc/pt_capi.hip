@@ -105,6 +105,7 @@ struct PtRenderer {
   DevBuf dRgba8, dF32, dScratch; // dScratch: see kScratchBytes
   DevBuf dTileOrder;             // 3 x numTiles tile indices (one list per cost class)
   int tileOrder = 2;             // PT_OPT_TILE_ORDER: 0 off, 1 on, 2 decided per frame
+  float ellCenterMax = 0.0f, ellScale = 0.0f; // see FrameParams
   bool sceneBounces = false;     // some object's material sends the path on (mirror or transparent)
   int tune = 0;
   void *extRgba8 = nullptr, *extF32 = nullptr;
@@ -259,6 +260,8 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     if (P.coop) ldsBytes += coopBytes;
   }
   P.sceneHuge = r->sceneHuge ? 1 : 0;
+  P.ellCenterMax = r->ellCenterMax;
+  P.ellScale = r->ellScale;
   P.volumeFilter = r->volumeFilter;
   P.sampleIndex = r->sampleIndex;
   if (r->accumulate) {
@@ -527,6 +530,27 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
 
   r->sceneHuge = sceneHuge;
+  {
+    // Magnitude bounds for the deferred ellipsoid path.  |rotate(v)| <= |v| (1 + 2|q||qw| + 2|q|^2).
+    float cMax = 0.0f, scale = 0.0f;
+    bool ok = true;
+    for (int i = 0; i < num_ellipsoids; ++i) {
+      const PtGPUEllipsoid &e = ellipsoids[i];
+      float qn = 0.0f;
+      for (int k = 0; k < 3; ++k) {
+        const float c = std::fabs(e.center[k]), rad = std::fabs(e.radii[k]);
+        if (!(c <= 1.0e9f) || !(rad >= 1.0e-9f && rad <= 1.0e9f)) ok = false;
+        cMax = std::max(cMax, c);
+        qn += e.rotation[k] * e.rotation[k];
+      }
+      const float qw = std::fabs(e.rotation[3]);
+      if (!(qn <= 1.0e6f) || !(qw <= 1.0e3f)) { ok = false; continue; }
+      const float grow = 1.0f + 2.0f * std::sqrt(qn) * qw + 2.0f * qn;
+      for (int k = 0; k < 3; ++k) scale = std::max(scale, grow / std::fabs(e.radii[k]));
+    }
+    r->ellCenterMax = ok ? cMax : 0.0f;
+    r->ellScale = ok ? 2.0f * scale : INFINITY; // 2: slack for the three-term sums
+  }
   r->sceneBounces = false;
   auto bounces = [&](int m) { return materials[m].diffuseSpecularShiny[3] > 0.01f || materials[m].transparencyEmissive[0] > 0.01f; };
   for (int i = 0; i < num_spheres && !r->sceneBounces; ++i) r->sceneBounces = bounces(spheres[i].materialIndex);

@@ -50,6 +50,8 @@ struct FrameParams {
   int maxBounces;
   int tilesX, numTiles;
   int sceneHuge;         // 1: some sphere has a non-finite or > 1e9 coordinate (no fast path)
+  float ellCenterMax;    // largest |centre coordinate| over the ellipsoids
+  float ellScale;        // bound on (1/radius) x (growth under rotateByQuaternion) over the ellipsoids; +inf: no deferral
   // volume 0 (raytrace.comp:538-550); boxMin/boxMax/extent precomputed
   float volPos[3], v0[3], v1[3], boxMin[3], boxMax[3], extent[3];
   int res[3];
@@ -514,6 +516,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     const bool live = state != ST_IDLE;
     float bestT = rTmax;
     int bestIdx = -1;
+    bool qLane = false; // this lane's ellipsoid roots may be deferred (set below)
     {
       const float tMin = kEpsilon; // every ray of the shader uses tMin = EPSILON
       const float kBig = 1.0e9f;   // |coordinates| up to here cannot overflow the discriminant
@@ -533,7 +536,14 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0 && !sparse;
       const bool special = live && !fastLane;
       // lanes whose ellipsoid roots can be deferred too: finite ray with a usable direction
-      const bool qLane = live && finiteRay && P.sceneHuge == 0 && dLen2 >= 1.0e-30f;
+      // ... and magnitudes for which no intermediate of hitEllipsoid can overflow (ellScale bounds
+      // 1/radii times the growth under the rotation over all ellipsoids; it is infinite when
+      // an ellipsoid has a zero, non-finite or huge parameter).  Other rays keep the shader's
+      // sequential loop below, where an infinity or a NaN does what it does in the shader.
+      const float oMax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(rO.x), __builtin_fabsf(rO.y)), __builtin_fabsf(rO.z));
+      const float dMax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(rD.x), __builtin_fabsf(rD.y)), __builtin_fabsf(rD.z));
+      qLane = live && finiteRay && P.sceneHuge == 0 && dLen2 >= 1.0e-30f &&
+              (oMax + P.ellCenterMax) * P.ellScale <= 1.0e8f && dMax * P.ellScale <= 1.0e8f;
       if (COUNT && live) cRays++;
       if (COUNT && special) cExact++;
       // slot[lane] = (bits(t) << 32) | ~(index + 1) of the best accepted object so
@@ -932,7 +942,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         if (qTail > qHead) { drainE(qTail - qHead); qHead = qTail; }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (qLane) {
+      if (qLane || fastLane) { // the slot holds the spheres' winner, and the ellipsoids' if they were deferred
         const unsigned long long kbest = w_slot[lane];
         const unsigned int widx = ~(unsigned int)kbest - 1u; // none -> 0xFFFFFFFF
         if (widx < (unsigned int)(Ns + Ne)) {
@@ -943,10 +953,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     }
 
     // Rays that are not finite keep the shader's sequential loop, NaN rules and all.
-    const bool seqEll = live && !(__builtin_fabsf(rO.x) <= 1.0e9f && __builtin_fabsf(rO.y) <= 1.0e9f &&
-                                  __builtin_fabsf(rO.z) <= 1.0e9f && __builtin_fabsf(rD.x) <= 1.0e9f &&
-                                  __builtin_fabsf(rD.y) <= 1.0e9f && __builtin_fabsf(rD.z) <= 1.0e9f &&
-                                  P.sceneHuge == 0 && dot3(rD, rD) >= 1.0e-30f);
+    const bool seqEll = live && !qLane;
 
     if (__ballot(seqEll) != 0ull && seqEll) {
       const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
