@@ -1048,9 +1048,12 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         step = GO_NEXT_EM_ELLIPSOID;
       }
 
-      while (step != GO_EMITTED) {
-        switch (step) {
-        case GO_PATH_RESULT: {
+      // The steps only ever lead forward (path result -> lights -> emissive spheres ->
+      // emissive ellipsoids -> after lighting -> finish), so one sweep over them in that
+      // order takes every lane to its next ray or to the end of its pixel, and lanes
+      // that reach a step by different routes share one execution of it.
+      {
+        if (step == GO_PATH_RESULT) do {
           // traceIterative body after traceRay (raytrace.comp:612-680)
           // --- rayMarchVolume(currentRay, hit ? rec.t : MAX_DISTANCE, 0) (:534-585) ---
           float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
@@ -1243,10 +1246,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             k = 0;
             step = GO_NEXT_LIGHT;
           }
-          break;
-        }
-        case GO_NEXT_LIGHT:
-        case GO_NEXT_TOON_LIGHT: {
+        } while (0);
+        if (step == GO_NEXT_LIGHT || step == GO_NEXT_TOON_LIGHT) do {
           if (k < L.numLights) { // getShadowFactor (:243-253)
             const float4 L = PT_LIGHT(k);
             const V3 lightVec = sub3(xyz(L), hitP);
@@ -1268,9 +1269,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             lit = add3(lit, em);
             step = GO_AFTER_LIGHTING;
           }
-          break;
-        }
-        case GO_NEXT_EM_SPHERE: { // raytrace.comp:367-443, over the precomputed emissive list
+        } while (0);
+        if (step == GO_NEXT_EM_SPHERE) do { // raytrace.comp:367-443, over the precomputed emissive list
           step = GO_NEXT_EM_ELLIPSOID;
           while (k < L.numEmSpheres) {
             const float4 s = PT_EMS(k, 0), sm = PT_EMS(k, 1), sx = PT_EMS(k, 2);
@@ -1316,9 +1316,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             k++;
           }
           if (step != GO_EMITTED) k = 0;
-          break;
-        }
-        case GO_NEXT_EM_ELLIPSOID: { // raytrace.comp:445-480
+        } while (0);
+        if (step == GO_NEXT_EM_ELLIPSOID) do { // raytrace.comp:445-480
           step = GO_AFTER_LIGHTING;
           while (k < L.numEmEllipsoids) {
             const float4 e0 = PT_EME(k, 0), em = PT_EME(k, 1), ex = PT_EME(k, 2);
@@ -1341,9 +1340,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             }
             k++;
           }
-          break;
-        }
-        case GO_AFTER_LIGHTING: { // raytrace.comp:645-671
+        } while (0);
+        if (step == GO_AFTER_LIGHTING) do { // raytrace.comp:645-671
           const float4 m1 = PT_MAT(hitMat, 1);
           const float4 m2 = PT_MAT(hitMat, 2);
           const float transparency = m2.x;
@@ -1378,9 +1376,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               step = GO_EMITTED;
             }
           }
-          break;
-        }
-        case GO_FINISH: { // main() :703-704
+        } while (0);
+        if (step == GO_FINISH) do { // main() :703-704
           float r = glclamp(fin.x, 0.0f, 1.0f), g = glclamp(fin.y, 0.0f, 1.0f), b = glclamp(fin.z, 0.0f, 1.0f);
           if (P.accum) { // mean of the clamped samples so far
             float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1396,12 +1393,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           if (P.outF32) P.outF32[outIdx] = make_float4(r, g, b, 1.0f);
           state = ST_IDLE;
           step = GO_EMITTED;
-          break;
-        }
-        default:
-          step = GO_EMITTED;
-          break;
-        }
+        } while (0);
       }
     }
     PT_PHASE(cycShade)
