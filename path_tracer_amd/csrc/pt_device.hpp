@@ -192,15 +192,21 @@ __device__ __forceinline__ uint32_t unorm8(float c) {
   return (uint32_t)(int)__builtin_rintf(c * 255.0f);
 }
 
-// Pixel w (0..63) of tile `tile`: x, local row ly (row of the compact band-major
-// frame) and full-frame row gy.  False when the pixel lies outside the frame.
-__device__ __forceinline__ bool tile_pixel(const FrameParams &P, int tile, int w, int &x, int &ly, int &gy) {
-  const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+// Pixel w (0..63) of the tile in tile column tx, tile row ty: x, local row ly (row of
+// the compact band-major frame) and full-frame row gy.  False when the pixel lies
+// outside the frame.
+__device__ __forceinline__ bool tile_pixel_xy(const FrameParams &P, int tx, int ty, int w, int &x, int &ly, int &gy) {
   x = tx * kTileDim + (w & 7);
   ly = ty * kTileDim + (w >> 3);
-  const int band = ly / P.bandRows;
-  gy = (band * P.bandCount + P.bandIndex) * P.bandRows + (ly - band * P.bandRows);
+  gy = ly;
+  if (P.bandCount > 1) {
+    const int band = ly / P.bandRows;
+    gy = (band * P.bandCount + P.bandIndex) * P.bandRows + (ly - band * P.bandRows);
+  }
   return x < P.width && ly < P.localRows && gy < P.height;
+}
+__device__ __forceinline__ bool tile_pixel(const FrameParams &P, int tile, int w, int &x, int &ly, int &gy) {
+  return tile_pixel_xy(P, tile % P.tilesX, tile / P.tilesX, w, x, ly, gy);
 }
 
 // createCameraRay for pixel (x, gy) (raytrace.comp:121-140 with main()'s uv, :692-700)
@@ -372,7 +378,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   // wave-uniform tile pool
   const int homeGroup = (int)(blockIdx.x & (kTicketGroups - 1));
   int groupsTried = 0; // ticket groups this wave has found drained
-  int poolNext = 0, poolEnd = 0;
+  int poolNext = 0, poolEnd = 0; // pixels [poolNext, poolEnd) of the tile at (poolTx, poolTy) are still to hand out
+  int poolTx = 0, poolTy = 0;
   bool exhausted = false;
   unsigned int nClass2 = 0, nClass1 = 0; // drawing order: tickets [0,n2) class 2, [n2,n2+n1) class 1, rest class 0
   if (P.tileOrder) {
@@ -417,6 +424,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       const int nIdle = __popcll(idleMask);
       const int avail = poolEnd - poolNext;
       int nextBase = -1; // first pixel of the following tile, if one is needed and left
+      int nextTx = 0, nextTy = 0;
       if (nIdle > avail && !exhausted) {
         // Tickets come from kTicketGroups counters instead of one: group g owns
         // tickets g, g + G, g + 2G, ...  A single counter would see one same-address
@@ -449,17 +457,20 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             t = (unsigned int)__builtin_amdgcn_readfirstlane(P.tileOrder[at]);
           }
           nextBase = (int)t * kTilePixels;
+          nextTx = (int)(t % (unsigned int)P.tilesX); // once per tile, wave-uniform
+          nextTy = (int)(t / (unsigned int)P.tilesX);
         }
       }
       const int rank = __popcll(idleMask & laneMaskLt);
-      int p = -1;
+      int p = -1; // pixel within its tile
+      bool fromNext = false;
       if (state == ST_IDLE) {
-        if (rank < avail) p = poolNext + rank;
-        else if (nextBase >= 0) p = nextBase + (rank - avail); // nIdle <= 64 = one tile
+        if (rank < avail) p = (poolNext & (kTilePixels - 1)) + rank;
+        else if (nextBase >= 0) { p = rank - avail; fromNext = true; } // nIdle <= 64 = one tile
       }
       if (p >= 0) {
         int x, ly, gy;
-        if (tile_pixel(L, p / kTilePixels, p % kTilePixels, x, ly, gy)) {
+        if (tile_pixel_xy(L, fromNext ? nextTx : poolTx, fromNext ? nextTy : poolTy, p, x, ly, gy)) {
           // main() + createCameraRay (raytrace.comp:686-700, 121-140)
           curO = ld3(L.cam);
           curD = camera_dir(L, x, gy);
@@ -473,7 +484,12 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
       }
       if (nIdle > avail) {
-        if (nextBase >= 0) { poolNext = nextBase + (nIdle - avail); poolEnd = nextBase + kTilePixels; }
+        if (nextBase >= 0) {
+          poolNext = nextBase + (nIdle - avail);
+          poolEnd = nextBase + kTilePixels;
+          poolTx = nextTx;
+          poolTy = nextTy;
+        }
         else poolNext = poolEnd;
       } else {
         poolNext += nIdle;
@@ -1004,9 +1020,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const float4 L = PT_LIGHT(k);
           const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
           const V3 surfaceColor = xyz(m0);
-          const V3 lightVec = sub3(xyz(L), hitP);
-          const float distance = length3(lightVec);
-          const V3 lightDir = div3s(lightVec, distance);
+          // lightDir and distance are the shadow ray's direction and range: the same
+          // expressions on the same operands (getShadowFactor :245-247 vs :349-351)
+          const float distance = rTmax;
+          const V3 lightDir = rD;
           const float attenuation = L.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
           const float diffuseStrength = glmax(0.0f, dot3(hitN, lightDir));
           const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseStrength), attenuation);
@@ -1023,9 +1040,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const float4 L = PT_LIGHT(k);
           const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
           const V3 surfaceColor = xyz(m0);
-          const V3 lightVec = sub3(xyz(L), hitP);
-          const float distance = length3(lightVec);
-          const V3 lightDir = div3s(lightVec, distance);
+          const float distance = rTmax; // as above (toon.glsl:19 vs :22-25)
+          const V3 lightDir = rD;
           const float attenuation = L.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
           const float diffuseRaw = glmax(0.0f, dot3(hitN, lightDir));
           const float diffuseQuantized = diffuseRaw > 0.6f ? 1.0f : (diffuseRaw > 0.3f ? 0.5f : 0.0f);
