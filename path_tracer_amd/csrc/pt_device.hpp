@@ -92,6 +92,7 @@ struct FrameParams {
   int accumCount;   // with accum: number of samples in the sum after this launch
   float4 *accum;    // running sum of the clamped samples per pixel, or null
   int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
+  float unitTol;    // |dot(d,d) - 1| up to which a ray takes the dense sphere loop
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
   int tune; // experiment switches (bit mask), 0 in production; bit 0: no wave priorities
 };
@@ -542,9 +543,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // hitSphere assumes a unit direction.  After a few mirror bounces the
       // shader's own rounding feedback can leave |d| far from 1; such a ray has
       // a non-negative discriminant for most spheres, so it is cheaper to hand
-      // it to the exact routine than to let it flood the candidate queue.
+      // it to the exact routine than to let it flood the candidate queue.  (Only
+      // a question of speed: the dense loop computes hitSphere's discriminant
+      // whatever |d| is.)
       const float dLen2 = dot3(rD, rD);
-      const bool unitDir = __builtin_fabsf(dLen2 - 1.0f) <= 2.0e-3f;
+      const bool unitDir = __builtin_fabsf(dLen2 - 1.0f) <= P.unitTol;
       // With only a few rays left in the wave (the end of the frame), the dense
       // loop would still cost a full pass; those rays go through the exact
       // routine instead, whose cost is per ray.
