@@ -72,7 +72,8 @@ class Runner:
     compact frame is read back and gathered through host memory.
     """
 
-    def __init__(self, scene, rank: int, world: int, device: int, torch_mod=None, dist=None, backend="nccl"):
+    def __init__(self, scene, rank: int, world: int, device: int, torch_mod=None, dist=None, backend="nccl",
+                 split: bool = None):
         from path_tracer_amd import HipRenderer
         from path_tracer_amd.distributed import BandGather
 
@@ -84,21 +85,25 @@ class Runner:
         self.r.setOption(1, 0)  # PT_OPT_FLOAT_OUTPUT off: the benchmark keeps the rgba8 frame only
         self.r.setScene(scene)
         self.pc = scene.push_constants()
-        self.bg = self.frame = None
-        if world > 1:
+        self.bg = self.frame = self.tstream = None
+        self.split = (world > 1) if split is None else split
+        if self.split:
             t = torch_mod
             self.r.setRowBands(BAND_ROWS, rank, world)
             dev = f"cuda:{device}" if backend == "nccl" else "cpu"
             self.bg = BandGather(t, dist, scene.width, scene.height, rank, world, dev, band_rows=BAND_ROWS)
             assert self.bg.local_rows == self.r.localRows()
             if backend == "nccl":
-                self.r.setStream(t.cuda.current_stream().cuda_stream)
+                # a stream of our own: the handle of torch's default stream is 0, which pt_set_stream
+                # reads as "back to the renderer's stream", and render, gather and assemble must be in order
+                self.tstream = t.cuda.Stream(device=dev)
+                self.r.setStream(self.tstream.cuda_stream)
                 self.r.setOutput(self.bg.local.data_ptr(), None)
                 if rank == 0:
                     self.frame = t.zeros((scene.height, scene.width, 4), dtype=t.uint8, device=dev)
 
     def _reduce(self, values, op="sum"):
-        if self.world == 1:
+        if not self.split:
             return values
         t = self.torch
         dev = self.bg.local.device
@@ -111,9 +116,10 @@ class Runner:
 
     def step(self):
         self.r.render(self.pc)
-        if self.world > 1:
+        if self.split:
             if self.backend == "nccl":
-                self.bg.gather()
+                with self.torch.cuda.stream(self.tstream):
+                    self.bg.gather()
                 if self.rank == 0:
                     self.r.assembleBands(self.bg.gathered.data_ptr(), self.frame.data_ptr(), 4, BAND_ROWS, self.world,
                                          self.bg.stride_rows)
@@ -126,11 +132,11 @@ class Runner:
 
     def sync(self):
         self.r.present()
-        if self.world > 1 and self.backend == "nccl":
+        if self.split and self.backend == "nccl":
             self.torch.cuda.synchronize()
 
     def barrier(self):
-        if self.world > 1:
+        if self.split:
             self.dist.barrier()
 
     def timed(self, steps: int, warmup: int):
@@ -155,7 +161,7 @@ class Runner:
 
     def final_frame(self):
         """Rank 0: the assembled (or whole) rgba8 frame as numpy."""
-        if self.world == 1:
+        if not self.split:
             return self.r.readbackRGBA8()
         if self.rank != 0:
             return None
@@ -235,14 +241,21 @@ def main():
                     help="collective backend for --gpus > 1 (gloo = host-memory rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the final frame against a single-GPU render")
+    ap.add_argument("--force-split", action="store_true",
+                    help="testing: take the band-split + gather path even with one rank (exercises the RCCL plumbing on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch_mod = dist = None
-    if world > 1:
+    if world > 1 or args.force_split:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist_mod
 
@@ -259,11 +272,11 @@ def main():
     n_gpus = world
 
     scene = build_scene(args.workload, args.scale)
-    run = Runner(scene, rank, world, local_rank, torch_mod, dist, args.backend)
+    run = Runner(scene, rank, world, local_rank, torch_mod, dist, args.backend, split=(world > 1 or args.force_split))
     cnt = run.counters()
     dt, ev_ms = run.timed(args.steps, args.warmup)
     check = None
-    if args.check and world > 1:
+    if args.check and (world > 1 or args.force_split):
         frame = run.final_frame()
         if rank == 0:
             solo = Runner(scene, 0, 1, local_rank)
@@ -344,7 +357,7 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
