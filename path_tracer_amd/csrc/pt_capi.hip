@@ -284,7 +284,11 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
 
   PT_HIP_CHECK(hipMemsetAsync(r->dScratch.p, 0, kScratchBytes, r->stream));
   if (P.tileOrder) {
-    hipLaunchKernelGGL(ptdev::pt_tile_order_kernel, dim3((P.numTiles + 255) / 256), dim3(256), 0, r->stream, P);
+    const size_t stage = ((size_t)pc->numSpheres + 4 * (size_t)pc->numEllipsoids) * sizeof(float4);
+    if (stage <= 48 * 1024)
+      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<true>, dim3((P.numTiles + 63) / 64), dim3(64), stage, r->stream, P);
+    else
+      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<false>, dim3((P.numTiles + 63) / 64), dim3(64), 0, r->stream, P);
     PT_HIP_CHECK(hipGetLastError());
   }
   dim3 grid(blocks), block(threads);

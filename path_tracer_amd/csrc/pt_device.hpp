@@ -236,7 +236,16 @@ __device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) {
 // not end on them.  Only the ORDER of the tiles depends on this pass; what is
 // drawn for each pixel does not, so nothing here needs the render kernel's
 // exact arithmetic.
-__global__ void __launch_bounds__(256) pt_tile_order_kernel(const FrameParams P) {
+template <bool STAGED>
+__global__ void __launch_bounds__(64) pt_tile_order_kernel(const FrameParams P) {
+  // STAGED: the spheres and ellipsoid records are copied to LDS first (the loops below
+  // would otherwise wait for one dependent global load per object)
+  extern __shared__ float4 s_objs[];
+  if (STAGED) {
+    for (int i = threadIdx.x; i < P.numSpheres; i += blockDim.x) s_objs[i] = P.spheres[i];
+    for (int i = threadIdx.x; i < 4 * P.numEllipsoids; i += blockDim.x) s_objs[P.numSpheres + i] = P.image[P.offEll + i];
+    __syncthreads();
+  }
   const int tileRaw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool inRange = tileRaw < P.numTiles;
   const int tile = inRange ? tileRaw : P.numTiles - 1;
@@ -245,31 +254,32 @@ __global__ void __launch_bounds__(256) pt_tile_order_kernel(const FrameParams P)
   if (x >= P.width) x = P.width - 1;
   if (gy >= P.height) gy = P.height - 1;
   const V3 o = ld3(P.cam), d = camera_dir(P, x, gy);
+  // approximate square roots and reciprocals are good enough to rank tiles
   float best = kMaxDistance;
   int bestIdx = -1;
   for (int i = 0; i < P.numSpheres; ++i) {
-    const float4 sp = P.spheres[i];
+    const float4 sp = STAGED ? s_objs[i] : P.spheres[i];
     const V3 oc = sub3(o, xyz(sp));
     const float hb = dot3(oc, d);
     const float disc = hb * hb - (dot3(oc, oc) - sp.w * sp.w);
     if (disc >= 0.0f) {
-      const float sq = __builtin_sqrtf(disc);
+      const float sq = __builtin_amdgcn_sqrtf(disc);
       float t = -hb - sq;
       if (t < kEpsilon) t = -hb + sq;
       if (t >= kEpsilon && t <= best) { best = t; bestIdx = i; }
     }
   }
   for (int j = 0; j < P.numEllipsoids; ++j) {
-    const float4 e0 = P.image[P.offEll + 4 * j], e1 = P.image[P.offEll + 4 * j + 1];
-    const float4 e2 = P.image[P.offEll + 4 * j + 2], e3 = P.image[P.offEll + 4 * j + 3];
+    const float4 *er = STAGED ? s_objs + P.numSpheres + 4 * j : P.image + P.offEll + 4 * j;
+    const float4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
     const V3 oc = mul3(rotate_q(sub3(o, xyz(e0)), xyz(e2), xyz(e3), e0.w), xyz(e1));
     const V3 dir = mul3(rotate_q(d, xyz(e2), xyz(e3), e0.w), xyz(e1));
     const float a = dot3(dir, dir), hb = dot3(oc, dir), c = dot3(oc, oc) - 1.0f;
     const float disc = hb * hb - a * c;
     if (disc >= 0.0f) {
-      const float sq = __builtin_sqrtf(disc);
-      float t = (-hb - sq) / a;
-      if (t < kEpsilon) t = (-hb + sq) / a;
+      const float sq = __builtin_amdgcn_sqrtf(disc), ia = __builtin_amdgcn_rcpf(a);
+      float t = (-hb - sq) * ia;
+      if (t < kEpsilon) t = (-hb + sq) * ia;
       if (t >= kEpsilon && t <= best) { best = t; bestIdx = P.numSpheres + j; }
     }
   }
@@ -292,16 +302,19 @@ __global__ void __launch_bounds__(256) pt_tile_order_kernel(const FrameParams P)
     }
     if (t0 <= t1) cls = 1;
   }
-  // one atomic per wave and class; lanes take consecutive places behind it
+  // one atomic per wave and class, the three issued together by lanes 0..2; the
+  // lanes of a class take consecutive places behind its counter value
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int c = 0; c < 3; ++c) {
-    const unsigned long long m = __ballot(inRange && cls == c);
-    if (m == 0ull) continue;
-    unsigned int base = 0;
-    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&P.classCount[c], (unsigned int)__popcll(m));
-    base = (unsigned int)__shfl((int)base, (int)__builtin_ctzll(m));
-    if (inRange && cls == c) P.tileOrder[c * P.numTiles + (int)(base + (unsigned int)__popcll(m & lt))] = tile;
+  const unsigned long long m0 = __ballot(inRange && cls == 0), m1 = __ballot(inRange && cls == 1),
+                           m2 = __ballot(inRange && cls == 2);
+  const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : m2);
+  unsigned int base = 0;
+  if (lane < 3 && mine != 0ull) base = atomicAdd(&P.classCount[lane], (unsigned int)__popcll(mine));
+  const unsigned int myBase = (unsigned int)__shfl((int)base, cls);
+  if (inRange) {
+    const unsigned long long m = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
+    P.tileOrder[cls * P.numTiles + (int)(myBase + (unsigned int)__popcll(m & lt))] = tile;
   }
 }
 
