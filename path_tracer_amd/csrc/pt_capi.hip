@@ -107,6 +107,10 @@ struct PtRenderer {
   int tileOrder = 2;             // PT_OPT_TILE_ORDER: 0 off, 1 on, 2 decided per frame
   float ellCenterMax = 0.0f, ellScale = 0.0f; // see FrameParams
   bool sceneBounces = false;     // some object's material sends the path on (mirror or transparent)
+  // Tuning switches for measurements (pt_set_option(100, bits); 0 = production, not part of the interface):
+  //   bit 0       no wave priorities            bit 4        no pooled end-of-frame tracing
+  //   bits 5-7    unit-direction tolerance x 2^n        bits 8-15   sparse-mode lane threshold + 1
+  //   bits 16-20  waves per workgroup, bits 21-23 workgroups per CU (0: chosen from the scene size)
   int tune = 0;
   void *extRgba8 = nullptr, *extF32 = nullptr;
   bool floatOutput = true;
@@ -249,7 +253,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   else if (objBytes <= 32 * 1024) { threads = 256; blocksPerCu = 4; }   // 4 x (32 + 4) KiB
   else if (objBytes <= 64 * 1024) { threads = 512; blocksPerCu = 2; }   // 2 x (64 + 8) KiB
   else { threads = 1024; blocksPerCu = 1; }                             // 1 x (<=144 + 16) KiB
-  if ((r->tune >> 16) & 0xff) { threads = 64 * ((r->tune >> 16) & 0x1f); blocksPerCu = std::max(1, (r->tune >> 21) & 7); } // experiment: waves per group, groups per CU
+  if ((r->tune >> 16) & 0xff) { threads = 64 * ((r->tune >> 16) & 0x1f); blocksPerCu = std::max(1, (r->tune >> 21) & 7); }
   size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15); // + the kernel's copy of the frame constants
   // Pooled tracing at the end of the frame pays when one pass over the spheres is long.
   {
@@ -746,7 +750,7 @@ int pt_set_option(PtRenderer *r, int option, int value) {
     if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_TILE_ORDER takes 0, 1 or 2");
     r->tileOrder = value;
     return PT_OK;
-  case 100: r->tune = value; return PT_OK; // experiment switches, not part of the interface
+  case 100: r->tune = value; return PT_OK; // tuning switches, see PtRenderer::tune
   case PT_OPT_OBJECT_SOURCE:
     if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: object source must be 0, 1 or 2");
     r->objectSource = value;

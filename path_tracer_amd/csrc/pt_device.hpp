@@ -94,7 +94,7 @@ struct FrameParams {
   int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
   float unitTol;    // |dot(d,d) - 1| up to which a ray takes the dense sphere loop
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
-  int tune; // experiment switches (bit mask), 0 in production; bit 0: no wave priorities
+  int tune;         // tuning switches of pt_set_option(100, ...), 0 in production; the kernel reads bit 0: no wave priorities
 };
 
 struct V3 { float x, y, z; };
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 
   unsigned int cRays = 0, cPath = 0, cLight = 0, cEmis = 0, cShaded = 0, cVoxel = 0;
   unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
-  unsigned int cGroups = 0, cSlow = 0;  // wave-level: 4-sphere trips, trips that left the fast path
+  unsigned int cGroups = 0, cSlow = 0;  // wave-level: 8-sphere trips, trips with at least one root
   unsigned int cExact = 0;              // rays this lane sent to the exact routine
   unsigned long long tPooled = 0, nPooled = 0, nPooledRays = 0;
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums

@@ -1,4 +1,4 @@
-"""A/B timing: python scratch/ab.py <workload> <opt>=<v1,v2,..> [frames]  -> median/min ms per option value, interleaved."""
+"""A/B timing: python tools/probes/ab.py <workload> <opt>=<v1,v2,..> [frames]  -> median/min ms per option value, interleaved."""
 import sys, numpy as np
 sys.path.insert(0,'.')
 from path_tracer_amd import scenes, HipRenderer
