@@ -40,6 +40,12 @@ enum {
   PT_OPT_VOLUME_FILTER = 5, /* 0 (default): nearest-neighbour voxel sampling as in the
                                reference (shaders/raytrace.comp:485-517); 1: trilinear
                                (a quality mode of this library, no counterpart there)  */
+  PT_OPT_FRAMES_IN_FLIGHT = 6, /* 2 (default, the reference's MAX_FRAMES_IN_FLIGHT, src/VulkanRenderer.cpp
+                               :1080-1100): consecutive pt_render calls alternate between two
+                               streams and two sets of output frames, so a frame starts while the
+                               previous one finishes; pt_present waits for both, readback and
+                               pt_device_* show the most recent frame.  1: one frame at a time.
+                               A caller's stream or output buffers imply 1.                      */
   PT_OPT_TILE_ORDER = 3     /* 1: a short pass before each frame sorts the 8x8 tiles so
                                that those whose pixels cast the longest chains of rays
                                are drawn first; 0: index order; 2 (default): sorted

@@ -80,8 +80,14 @@ struct PtRenderer {
   int computeUnits = 0;
   char deviceName[256] = {0};
   hipStream_t ownStream = nullptr;
-  hipStream_t stream = nullptr;
-  hipEvent_t evBegin = nullptr, evEnd = nullptr;
+  hipStream_t stream = nullptr;      // ownStream, or the caller's (pt_set_stream)
+  hipStream_t ownStream2 = nullptr;  // second frame in flight (slot 1)
+  hipEvent_t evBegin = nullptr, evEnd = nullptr, evCross = nullptr;
+  // Two frames in flight (reference src/VulkanRenderer.cpp:1080-1100, MAX_FRAMES_IN_FLIGHT = 2): plain
+  // pt_render calls alternate between two slots, each with its own stream, output frames and scratch,
+  // so the next frame fills the compute units the tail of the previous one leaves idle.
+  int framesInFlight = 2;            // PT_OPT_FRAMES_IN_FLIGHT
+  int lastSlot = 0;                  // slot of the most recent frame (what readback and pt_device_* show)
 
   // scene
   bool sceneValid = false;
@@ -102,8 +108,8 @@ struct PtRenderer {
   PtGPUVolumetricData volume0{};
 
   // output
-  DevBuf dRgba8, dF32, dScratch; // dScratch: see kScratchBytes
-  DevBuf dTileOrder;             // 3 x numTiles tile indices (one list per cost class)
+  DevBuf dRgba8[2], dF32[2], dScratch[2]; // per slot; dScratch: see kScratchBytes
+  DevBuf dTileOrder[2];                   // 3 x numTiles tile indices (one list per cost class)
   int tileOrder = 2;             // PT_OPT_TILE_ORDER: 0 off, 1 on, 2 decided per frame
   float ellCenterMax = 0.0f, ellScale = 0.0f; // see FrameParams
   bool sceneBounces = false;     // some object's material sends the path on (mirror or transparent)
@@ -140,12 +146,25 @@ int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {
   return rows;
 }
 
-int ensure_outputs(PtRenderer *r) {
+int ensure_outputs(PtRenderer *r, int slot) {
   size_t px = (size_t)r->width * (size_t)std::max(r->localRows, 1);
-  if (!r->extRgba8) PT_HIP_CHECK(r->dRgba8.reserve(px * 4));
-  if (r->floatOutput && !r->extF32 && !r->extRgba8) PT_HIP_CHECK(r->dF32.reserve(px * 16));
-  PT_HIP_CHECK(r->dScratch.reserve(kScratchBytes));
+  if (!r->extRgba8) PT_HIP_CHECK(r->dRgba8[slot].reserve(px * 4));
+  if (r->floatOutput && !r->extF32 && !r->extRgba8) PT_HIP_CHECK(r->dF32[slot].reserve(px * 16));
+  PT_HIP_CHECK(r->dScratch[slot].reserve(kScratchBytes));
   return PT_OK;
+}
+
+int sync_all(PtRenderer *r) {
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  if (r->ownStream2) PT_HIP_CHECK(hipStreamSynchronize(r->ownStream2));
+  return PT_OK;
+}
+
+// Plain frames may alternate between the two slots unless something ties them to one
+// target: a caller's stream or output buffers, or the running sum of pt_render_samples.
+bool pipelined(const PtRenderer *r) {
+  return r->framesInFlight == 2 && r->stream == r->ownStream && !r->extRgba8 && !r->accumulate && r->ownStream2;
 }
 
 int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: the kernel's MODE (0 plain, 1 counting, 2 phase cycles)
@@ -156,7 +175,9 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
       pc->numVolumes < 0 || pc->numVolumes > r->numVolumes)
     return fail(PT_ERR_INVALID, "pt_render: push-constant object counts exceed the uploaded scene");
   PT_HIP_CHECK(hipSetDevice(r->device));
-  int rc = ensure_outputs(r);
+  const int slot = (mode == 0 && pipelined(r)) ? (r->lastSlot ^ 1) : 0;
+  const hipStream_t stream = slot ? r->ownStream2 : r->stream;
+  int rc = ensure_outputs(r, slot);
   if (rc != PT_OK) return rc;
 
   ptdev::FrameParams P;
@@ -221,10 +242,10 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     P.brickX = (r->brickRes[0] + 7) / 8;
     P.brickY = (r->brickRes[1] + 7) / 8;
   }
-  P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8.p);
-  P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr));
-  P.tileCounter = (unsigned int *)((char *)r->dScratch.p + 512);
-  P.counters = (unsigned long long *)((char *)r->dScratch.p + 64);
+  P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8[slot].p);
+  P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32[slot].p : nullptr));
+  P.tileCounter = (unsigned int *)((char *)r->dScratch[slot].p + 512);
+  P.counters = (unsigned long long *)((char *)r->dScratch[slot].p + 64);
 
   if (P.numTiles <= 0) return PT_OK;
   // The ordering pass pays off when pixels differ a lot in the number of rays
@@ -234,9 +255,9 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
       (r->tileOrder == 2 && r->sceneBounces && P.maxBounces > 1 &&
        (long long)(pc->numSpheres + pc->numEllipsoids) * P.numTiles <= 50000000ll);
   if (orderTiles) {
-    PT_HIP_CHECK(r->dTileOrder.reserve((size_t)P.numTiles * 3 * sizeof(int)));
-    P.tileOrder = (int *)r->dTileOrder.p;
-    P.classCount = (unsigned int *)((char *)r->dScratch.p + 16);
+    PT_HIP_CHECK(r->dTileOrder[slot].reserve((size_t)P.numTiles * 3 * sizeof(int)));
+    P.tileOrder = (int *)r->dTileOrder[slot].p;
+    P.classCount = (unsigned int *)((char *)r->dScratch[slot].p + 16);
   }
 
   // Launch geometry: persistent workgroups, 16 waves per CU.  Objects are
@@ -286,13 +307,13 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
   int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
 
-  PT_HIP_CHECK(hipMemsetAsync(r->dScratch.p, 0, kScratchBytes, r->stream));
+  PT_HIP_CHECK(hipMemsetAsync(r->dScratch[slot].p, 0, kScratchBytes, stream));
   if (P.tileOrder) {
     const size_t stage = ((size_t)pc->numSpheres + 4 * (size_t)pc->numEllipsoids) * sizeof(float4);
     if (stage <= 48 * 1024)
-      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<true>, dim3((P.numTiles + 63) / 64), dim3(64), stage, r->stream, P);
+      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<true>, dim3((P.numTiles + 63) / 64), dim3(64), stage, stream, P);
     else
-      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<false>, dim3((P.numTiles + 63) / 64), dim3(64), 0, r->stream, P);
+      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<false>, dim3((P.numTiles + 63) / 64), dim3(64), 0, stream, P);
     PT_HIP_CHECK(hipGetLastError());
   }
   dim3 grid(blocks), block(threads);
@@ -300,13 +321,14 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   if (useLds) {                                                                                              \
     PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, true>,                     \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));            \
-    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, true>), grid, block, ldsBytes, r->stream, P);         \
+    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, true>), grid, block, ldsBytes, stream, P);            \
   } else {                                                                                                   \
-    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, false>), grid, block, ldsBytes, r->stream, P);        \
+    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, false>), grid, block, ldsBytes, stream, P);           \
   }
   if (mode == 1) { PT_LAUNCH(1) } else if (mode == 2) { PT_LAUNCH(2) } else { PT_LAUNCH(0) }
 #undef PT_LAUNCH
   PT_HIP_CHECK(hipGetLastError());
+  r->lastSlot = slot;
   r->lastBlocks = blocks;
   r->lastThreads = threads;
   r->lastLds = (int)ldsBytes;
@@ -348,9 +370,12 @@ int pt_create(int width, int height, int device, PtRenderer **out) {
   e = hipStreamCreateWithFlags(&r->ownStream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   r->stream = r->ownStream;
+  e = hipStreamCreateWithFlags(&r->ownStream2, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   (void)hipEventCreate(&r->evBegin);
   (void)hipEventCreate(&r->evEnd);
-  int rc = ensure_outputs(r);
+  (void)hipEventCreateWithFlags(&r->evCross, hipEventDisableTiming);
+  int rc = ensure_outputs(r, 0);
   if (rc != PT_OK) { pt_destroy(r); return rc; }
   *out = r;
   return PT_OK;
@@ -360,11 +385,15 @@ void pt_destroy(PtRenderer *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8, &r->dF32, &r->dScratch, &r->dTileOrder, &r->dBricks, &r->dAccum};
+  if (r->ownStream2) (void)hipStreamSynchronize(r->ownStream2);
+  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8[0], &r->dRgba8[1], &r->dF32[0], &r->dF32[1],
+                    &r->dScratch[0], &r->dScratch[1], &r->dTileOrder[0], &r->dTileOrder[1], &r->dBricks, &r->dAccum};
   for (DevBuf *b : bufs) b->release();
   if (r->evBegin) (void)hipEventDestroy(r->evBegin);
   if (r->evEnd) (void)hipEventDestroy(r->evEnd);
+  if (r->evCross) (void)hipEventDestroy(r->evCross);
   if (r->ownStream) (void)hipStreamDestroy(r->ownStream);
+  if (r->ownStream2) (void)hipStreamDestroy(r->ownStream2);
   delete r;
 }
 
@@ -395,9 +424,11 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
         (long long)v.resolution_x * v.resolution_y * v.resolution_z > 0x7fffffffll)
       return fail(PT_ERR_INVALID, "pt_update_scene: volume 0 resolution must be positive with fewer than 2^31 voxels");
   }
-  PT_HIP_CHECK(hipSetDevice(r->device));
-  // The previous frame may still be reading the buffers we are about to refill.
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  // The frames in flight may still be reading the buffers we are about to refill.
+  {
+    int rcSync = sync_all(r);
+    if (rcSync != PT_OK) return rcSync;
+  }
 
   // AoS records -> one scene image (see FrameParams in pt_device.hpp) + the plain sphere array.
   if (num_materials > 65536) return fail(PT_ERR_INVALID, "pt_update_scene: more than 65536 materials");
@@ -613,43 +644,41 @@ int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counte
   int rc = launch_frame(r, pc, 1);
   if (rc != PT_OK) return rc;
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
-  PT_HIP_CHECK(hipMemcpy(counters, (char *)r->dScratch.p + 64, PT_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  PT_HIP_CHECK(hipMemcpy(counters, (char *)r->dScratch[0].p + 64, PT_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
   // the per-phase cycle sums come from a second frame drawn by the production code with timers only
   rc = launch_frame(r, pc, 2);
   if (rc != PT_OK) return rc;
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
   uint64_t cyc[PT_CNT_COUNT];
-  PT_HIP_CHECK(hipMemcpy(cyc, (char *)r->dScratch.p + 64, sizeof cyc, hipMemcpyDeviceToHost));
+  PT_HIP_CHECK(hipMemcpy(cyc, (char *)r->dScratch[0].p + 64, sizeof cyc, hipMemcpyDeviceToHost));
   for (int i = PT_CNT_CYC_REFILL; i < PT_CNT_COUNT; ++i) counters[i] = cyc[i];
   return PT_OK;
 }
 
 int pt_present(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_present: renderer is null");
-  PT_HIP_CHECK(hipSetDevice(r->device));
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
-  return PT_OK;
+  return sync_all(r);
 }
 
 int pt_readback_rgba8(PtRenderer *r, uint8_t *dst, size_t dst_bytes) {
   if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_rgba8: null argument");
   size_t bytes = (size_t)r->width * r->localRows * 4;
   if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_rgba8: destination too small");
-  PT_HIP_CHECK(hipSetDevice(r->device));
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
-  const void *src = r->extRgba8 ? r->extRgba8 : r->dRgba8.p;
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
+  const void *src = r->extRgba8 ? r->extRgba8 : r->dRgba8[r->lastSlot].p;
   PT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
 int pt_readback_f32(PtRenderer *r, float *dst, size_t dst_bytes) {
   if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_f32: null argument");
-  const void *src = r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr);
+  const void *src = r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32[r->lastSlot].p : nullptr);
   if (!src) return fail(PT_ERR_STATE, "pt_readback_f32: float output is disabled");
   size_t bytes = (size_t)r->width * r->localRows * 16;
   if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_f32: destination too small");
-  PT_HIP_CHECK(hipSetDevice(r->device));
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
   PT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return PT_OK;
 }
@@ -671,6 +700,7 @@ int pt_set_row_bands(PtRenderer *r, int band_rows, int band_index, int band_coun
   if (!r) return fail(PT_ERR_INVALID, "pt_set_row_bands: renderer is null");
   if (band_count < 1 || band_index < 0 || band_index >= band_count || (band_count > 1 && band_rows < 1))
     return fail(PT_ERR_INVALID, "pt_set_row_bands: need band_rows >= 1 and 0 <= band_index < band_count");
+  if (sync_all(r) != PT_OK) return PT_ERR_HIP; // the frame geometry changes under the frames in flight
   r->bandRows = band_rows;
   r->bandIndex = band_index;
   r->bandCount = band_count;
@@ -699,9 +729,9 @@ int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
   return PT_OK;
 }
 
-void *pt_device_rgba8(PtRenderer *r) { return r ? (r->extRgba8 ? r->extRgba8 : r->dRgba8.p) : nullptr; }
+void *pt_device_rgba8(PtRenderer *r) { return r ? (r->extRgba8 ? r->extRgba8 : r->dRgba8[r->lastSlot].p) : nullptr; }
 void *pt_device_f32(PtRenderer *r) {
-  return r ? (r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32.p : nullptr)) : nullptr;
+  return r ? (r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32[r->lastSlot].p : nullptr)) : nullptr;
 }
 
 int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev) {
@@ -714,19 +744,25 @@ int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev) {
 
 int pt_set_stream(PtRenderer *r, void *hip_stream) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_stream: renderer is null");
-  PT_HIP_CHECK(hipSetDevice(r->device));
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
   r->stream = hip_stream ? (hipStream_t)hip_stream : r->ownStream;
   return PT_OK;
 }
 
 int pt_timer_begin(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_timer_begin: renderer is null");
+  // after everything queued so far on either slot; nothing queued later starts before it
+  PT_HIP_CHECK(hipEventRecord(r->evCross, r->ownStream2));
+  PT_HIP_CHECK(hipStreamWaitEvent(r->stream, r->evCross, 0));
   PT_HIP_CHECK(hipEventRecord(r->evBegin, r->stream));
+  PT_HIP_CHECK(hipStreamWaitEvent(r->ownStream2, r->evBegin, 0));
   return PT_OK;
 }
 int pt_timer_end(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_timer_end: renderer is null");
+  PT_HIP_CHECK(hipEventRecord(r->evCross, r->ownStream2));
+  PT_HIP_CHECK(hipStreamWaitEvent(r->stream, r->evCross, 0));
   PT_HIP_CHECK(hipEventRecord(r->evEnd, r->stream));
   return PT_OK;
 }
@@ -742,6 +778,11 @@ int pt_set_option(PtRenderer *r, int option, int value) {
   switch (option) {
   case PT_OPT_FLOAT_OUTPUT: r->floatOutput = value != 0; return PT_OK;
   case PT_OPT_VOLUME_BRICKS: r->volumeBricks = value != 0; return PT_OK;
+  case PT_OPT_FRAMES_IN_FLIGHT:
+    if (value != 1 && value != 2) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_FRAMES_IN_FLIGHT takes 1 or 2");
+    if (sync_all(r) != PT_OK) return PT_ERR_HIP;
+    r->framesInFlight = value;
+    return PT_OK;
   case PT_OPT_VOLUME_FILTER:
     if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_VOLUME_FILTER takes 0 or 1");
     r->volumeFilter = value;

@@ -115,3 +115,4 @@ OPT_OBJECT_SOURCE = 2
 OPT_TILE_ORDER = 3
 OPT_VOLUME_BRICKS = 4
 OPT_VOLUME_FILTER = 5
+OPT_FRAMES_IN_FLIGHT = 6

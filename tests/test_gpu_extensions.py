@@ -127,3 +127,33 @@ def test_tile_order_and_object_source_do_not_change_the_frame():
         r.shutdown()
     for f in frames[1:]:
         np.testing.assert_array_equal(frames[0].view(np.uint32), f.view(np.uint32))
+
+
+def test_two_frames_in_flight_show_the_latest_frame():
+    """Consecutive pt_render calls alternate between two slots; what readback shows is always the
+    most recent frame, bit-identical to the same frame drawn one at a time."""
+    import copy
+
+    sc = scenes.config2(320, 180, n_spheres=16, n_ellipsoids=5, max_depth=4)
+    pcs = []
+    for k in range(4):
+        s2 = copy.copy(sc)
+        s2.camera_pos = (5.0 - 0.7 * k, 1.5 + 0.2 * k, 6.0)
+        pcs.append(s2.push_constants())
+    solo = _renderer(sc, {T.OPT_FRAMES_IN_FLIGHT: 1})
+    want = [_frame(solo, pc)[1].copy() for pc in pcs]
+    solo.shutdown()
+    assert not np.array_equal(want[0], want[1])
+    r = _renderer(sc, {T.OPT_FRAMES_IN_FLIGHT: 2})
+    for pc in pcs:          # four frames queued back to back, no wait in between
+        r.render(pc)
+    r.present()
+    np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[3].view(np.uint32))
+    for k in (1, 0, 2):     # and one by one, in another order
+        r.render(pcs[k])
+        np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[k].view(np.uint32))
+    cnt = r.renderCounted(pcs[0])  # the instrumented frame uses slot 0 whatever is in flight
+    assert int(cnt[0]) > 0
+    r.render(pcs[3])
+    np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[3].view(np.uint32))
+    r.shutdown()

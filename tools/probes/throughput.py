@@ -1,0 +1,20 @@
+"""Frames per timed region: python tools/probes/throughput.py <workload> <option>=<v1,v2,..> [frames] -> ms per frame."""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from path_tracer_amd import scenes, HipRenderer
+name = sys.argv[1]; opt, vals = sys.argv[2].split('='); opt = int(opt); vals = [int(v) for v in vals.split(',')]
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+sc = {'c3': scenes.config3, 'c2': scenes.config2, 'c4': scenes.config4}[name]()
+pc = sc.push_constants()
+for v in vals:
+    r = HipRenderer(); assert r.initialize(sc.width, sc.height)
+    r.setOption(1, 0); r.setOption(opt, v); r.setScene(sc)
+    res = []
+    for rep in range(4):
+        r.timerBegin()
+        for i in range(n):
+            r.render(pc)
+        r.timerEnd()
+        res.append(r.timerElapsedMs() / n)
+    print(f"{name} opt{opt}={v}: ms/frame over {n}-frame regions: " + ' '.join('%.3f' % x for x in res))
+    r.shutdown()
