@@ -380,6 +380,19 @@ def main():
                                     "pixel); rays per sample taken from sample 0"}
         result["workloads"] = extras
 
+    # N > 1: the 4K / 4096-sphere frame (the configuration the multi-GPU metric is quoted on) beside the default workload,
+    # same band split and gather; every rank takes part
+    if n_gpus > 1 and not args.no_extras and args.scale == 1.0 and args.workload != "c3":
+        sc = build_scene("c3")
+        rr = Runner(sc, rank, world, local_rank, torch_mod, dist, args.backend)
+        c = rr.counters()
+        d, e = rr.timed(5, 1)
+        rr.close()
+        if rank == 0:
+            result["workloads"] = {"c3": {"ms_per_frame": round(d / 5 * 1e3, 4), "Mrays_per_s": round(c[0] / (d / 5) / 1e6, 2),
+                                          "rays_per_frame": float(c[0]), "n_gpus": n_gpus,
+                                          "roofline": roofline_for(c / n_gpus, e / 5)}}
+
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(scene)
     elif rank == 0:
