@@ -73,7 +73,7 @@ class Runner:
     """
 
     def __init__(self, scene, rank: int, world: int, device: int, torch_mod=None, dist=None, backend="nccl",
-                 split: bool = None):
+                 split: bool = None, frames_in_flight: int = 2):
         from path_tracer_amd import HipRenderer
         from path_tracer_amd.distributed import BandGather
 
@@ -83,28 +83,34 @@ class Runner:
         if not self.r.initialize(scene.width, scene.height, device):
             raise SystemExit("renderer initialisation failed")
         self.r.setOption(1, 0)  # PT_OPT_FLOAT_OUTPUT off: the benchmark keeps the rgba8 frame only
-        # One frame at a time for the headline, the roofline and the profiles: a frame's kernel then runs alone and
-        # its duration means something.  The library's default (two frames in flight, like the reference's
-        # MAX_FRAMES_IN_FLIGHT) is measured separately, see pipelined().
-        self.r.setOption(6, 1)
+        self.set_frames_in_flight(frames_in_flight)
         self.r.setScene(scene)
         self.pc = scene.push_constants()
-        self.bg = self.frame = self.tstream = None
+        self.bgs, self.frames, self.tstreams = [], [], []
         self.split = (world > 1) if split is None else split
         if self.split:
             t = torch_mod
             self.r.setRowBands(BAND_ROWS, rank, world)
             dev = f"cuda:{device}" if backend == "nccl" else "cpu"
-            self.bg = BandGather(t, dist, scene.width, scene.height, rank, world, dev, band_rows=BAND_ROWS)
-            assert self.bg.local_rows == self.r.localRows()
-            if backend == "nccl":
-                # a stream of our own: the handle of torch's default stream is 0, which pt_set_stream
-                # reads as "back to the renderer's stream", and render, gather and assemble must be in order
-                self.tstream = t.cuda.Stream(device=dev)
-                self.r.setStream(self.tstream.cuda_stream)
-                self.r.setOutput(self.bg.local.data_ptr(), None)
-                if rank == 0:
-                    self.frame = t.zeros((scene.height, scene.width, 4), dtype=t.uint8, device=dev)
+            # one set of buffers per frame slot, so that a frame can be drawn while the previous one is gathered
+            for slot in range(2 if backend == "nccl" else 1):
+                bg = BandGather(t, dist, scene.width, scene.height, rank, world, dev, band_rows=BAND_ROWS)
+                assert bg.local_rows == self.r.localRows()
+                self.bgs.append(bg)
+                if backend == "nccl":
+                    # streams of our own: the handle of torch's default stream is 0, which the library reads as
+                    # "the renderer's own stream", and render, gather and assemble of a frame must stay in order
+                    ts = t.cuda.Stream(device=dev)
+                    self.tstreams.append(ts)
+                    self.r.setSlot(slot, ts.cuda_stream, bg.local.data_ptr(), None)
+                    self.frames.append(t.zeros((scene.height, scene.width, 4), dtype=t.uint8, device=dev)
+                                       if rank == 0 else None)
+            self.last = 0
+        self.bg = self.bgs[0] if self.bgs else None
+
+    def set_frames_in_flight(self, n: int):
+        self.frames_in_flight = n
+        self.r.setOption(6, n)
 
     def _reduce(self, values, op="sum"):
         if not self.split:
@@ -122,17 +128,19 @@ class Runner:
         self.r.render(self.pc)
         if self.split:
             if self.backend == "nccl":
-                with self.torch.cuda.stream(self.tstream):
-                    self.bg.gather()
-                if self.rank == 0:
-                    self.r.assembleBands(self.bg.gathered.data_ptr(), self.frame.data_ptr(), 4, BAND_ROWS, self.world,
-                                         self.bg.stride_rows)
+                slot = self.last = self.r.lastSlot()
+                bg = self.bgs[slot]
+                with self.torch.cuda.stream(self.tstreams[slot]):
+                    bg.gather()
+                if self.rank == 0:  # runs on the stream of the slot just drawn, behind its gather
+                    self.r.assembleBands(bg.gathered.data_ptr(), self.frames[slot].data_ptr(), 4, BAND_ROWS, self.world,
+                                         bg.stride_rows)
             else:
                 part = self.r.readbackRGBA8()
                 self.bg.local[:part.shape[0]] = self.torch.from_numpy(part)
                 self.bg.gather()
                 if self.rank == 0:
-                    self.frame = self.bg.assemble_host()
+                    self.host_frame = self.bg.assemble_host()
 
     def sync(self):
         self.r.present()
@@ -163,28 +171,13 @@ class Runner:
         dt = float(self._reduce([dt], "max")[0])
         return dt, ev_ms
 
-    def pipelined(self, steps: int):
-        """ms per frame with two frames in flight (single GPU): consecutive frames overlap, the next one fills the
-        compute units that the tail of the previous one leaves idle."""
-        self.r.setOption(6, 2)
-        for _ in range(2):
-            self.r.render(self.pc)
-        self.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.r.render(self.pc)
-        self.sync()
-        dt = time.perf_counter() - t0
-        self.r.setOption(6, 1)
-        return dt / steps * 1e3
-
     def final_frame(self):
         """Rank 0: the assembled (or whole) rgba8 frame as numpy."""
         if not self.split:
             return self.r.readbackRGBA8()
         if self.rank != 0:
             return None
-        return self.frame.cpu().numpy() if self.backend == "nccl" else self.frame
+        return self.frames[self.last].cpu().numpy() if self.backend == "nccl" else self.host_frame
 
     def close(self):
         self.r.shutdown()
@@ -260,6 +253,8 @@ def main():
                     help="collective backend for --gpus > 1 (gloo = host-memory rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the final frame against a single-GPU render")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+                    help="2 (default): consecutive frames overlap on two streams, as in the reference; 1: one at a time")
     ap.add_argument("--force-split", action="store_true",
                     help="testing: take the band-split + gather path even with one rank (exercises the RCCL plumbing on one GPU)")
     args = ap.parse_args()
@@ -291,23 +286,34 @@ def main():
     n_gpus = world
 
     scene = build_scene(args.workload, args.scale)
-    run = Runner(scene, rank, world, local_rank, torch_mod, dist, args.backend, split=(world > 1 or args.force_split))
+    fif = args.frames_in_flight
+    run = Runner(scene, rank, world, local_rank, torch_mod, dist, args.backend, split=(world > 1 or args.force_split),
+                 frames_in_flight=fif)
     cnt = run.counters()
+    # The headline: K frames in the library's production mode (two frames in flight like the reference's
+    # MAX_FRAMES_IN_FLIGHT unless --frames-in-flight 1).
     dt, ev_ms = run.timed(args.steps, args.warmup)
+    # The roofline leg: the same K frames one at a time, so that a launch's duration is that of a kernel running alone
+    # (and is what a rocprofv3 trace of `--frames-in-flight 1` shows).
+    if fif == 2:
+        run.set_frames_in_flight(1)
+        dt1, ev1_ms = run.timed(args.steps, 1)
+        run.set_frames_in_flight(2)
+    else:
+        dt1, ev1_ms = dt, ev_ms
     check = None
     if args.check and (world > 1 or args.force_split):
         frame = run.final_frame()
         if rank == 0:
-            solo = Runner(scene, 0, 1, local_rank)
+            solo = Runner(scene, 0, 1, local_rank, frames_in_flight=1)
             solo.step()
             solo.sync()
             check = bool(np.array_equal(frame, solo.final_frame()))
             solo.close()
     ms_per_step = dt / args.steps * 1e3
-    kernel_ms = ev_ms / args.steps
+    kernel_ms = ev1_ms / args.steps
     dev_name, cus = run.r.deviceInfo()
     launch = run.r.lastLaunch()
-    pipe_ms = run.pipelined(max(args.steps, 10)) if (world == 1 and not args.force_split and not args.no_extras) else None
     run.close()
 
     result = None
@@ -332,17 +338,20 @@ def main():
             "roofline": roofline_for(cnt / max(n_gpus, 1), kernel_ms,
                                      measured_traffic(args.workload) if args.scale == 1.0 else None) if n_gpus == 1 else None,
         }
-        if pipe_ms is not None:
-            result["pipelined"] = {"frames_in_flight": 2, "ms_per_step": round(pipe_ms, 4),
-                                   "value": round(float(cnt[6] if args.workload == "c4" else rays) / pipe_ms / 1e3, 2),
-                                   "unit": unit,
-                                   "note": "the library's default mode, as the reference's MAX_FRAMES_IN_FLIGHT = 2: consecutive "
-                                           "frames overlap on two streams; the headline value above is one frame at a time"}
+        result["frames_in_flight"] = fif
+        if fif == 2:
+            unit_count = float(cnt[6]) if args.workload == "c4" else rays
+            result["one_frame_at_a_time"] = {
+                "ms_per_step": round(dt1 / args.steps * 1e3, 4), "value": round(unit_count / (dt1 / args.steps) / 1e6, 2),
+                "unit": unit,
+                "note": "same frames with PT_OPT_FRAMES_IN_FLIGHT = 1; the roofline object and the rocprofv3 summaries "
+                        "describe this mode (a kernel running alone); the headline has two frames in flight, the "
+                        "library's default, as the reference's MAX_FRAMES_IN_FLIGHT = 2"}
         if check is not None:
             result["config"]["gathered_frame_equals_single_gpu_frame"] = check
         if n_gpus > 1:
             result["roofline"] = roofline_for(cnt / n_gpus, kernel_ms)
-            result["roofline"]["note"] += "; per-rank share, event time includes the gather"
+            result["roofline"]["note"] += "; per-rank share, one frame at a time, event time includes the gather"
 
     # side measurements (single GPU only): C3 and C4 frame times
     if n_gpus == 1 and not args.no_extras and args.scale == 1.0:
@@ -351,12 +360,13 @@ def main():
             if name == args.workload:
                 continue
             sc = build_scene(name)
-            rr = Runner(sc, 0, 1, local_rank)
+            rr = Runner(sc, 0, 1, local_rank, frames_in_flight=1)
             c = rr.counters()
             d, e = rr.timed(steps, 1)
-            pm = rr.pipelined(steps)
+            rr.set_frames_in_flight(2)
+            d2, _ = rr.timed(steps, 2)
             rr.close()
-            extras[name] = {"ms_per_frame": round(d / steps * 1e3, 4), "ms_per_frame_2_in_flight": round(pm, 4),
+            extras[name] = {"ms_per_frame": round(d / steps * 1e3, 4), "ms_per_frame_2_in_flight": round(d2 / steps * 1e3, 4),
                             "Mrays_per_s": round(c[0] / (d / steps) / 1e6, 2),
                             "rays_per_frame": float(c[0]), "roofline": roofline_for(c, e / steps, measured_traffic(name))}
             if name == "c4":
@@ -384,9 +394,9 @@ def main():
     # same band split and gather; every rank takes part
     if n_gpus > 1 and not args.no_extras and args.scale == 1.0 and args.workload != "c3":
         sc = build_scene("c3")
-        rr = Runner(sc, rank, world, local_rank, torch_mod, dist, args.backend)
+        rr = Runner(sc, rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=fif)
         c = rr.counters()
-        d, e = rr.timed(5, 1)
+        d, e = rr.timed(5, 2)
         rr.close()
         if rank == 0:
             result["workloads"] = {"c3": {"ms_per_frame": round(d / 5 * 1e3, 4), "Mrays_per_s": round(c[0] / (d / 5) / 1e6, 2),

@@ -160,6 +160,16 @@ int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev);
  * renderer's own stream. */
 int pt_set_stream(PtRenderer *r, void *hip_stream);
 
+/* Both at once, per frame slot (0 or 1): stream (NULL: the renderer's own) and
+ * output buffers (NULL: internal) of the frames drawn in that slot.  With
+ * PT_OPT_FRAMES_IN_FLIGHT = 2, consecutive pt_render calls alternate between the
+ * slots when both are set up alike (both internal, or both with the caller's
+ * stream and buffers); pt_set_stream / pt_set_output configure slot 0 only and so
+ * keep every frame in slot 0.  pt_last_slot tells which slot the most recent frame
+ * went to; pt_assemble_bands runs on that slot's stream. */
+int pt_set_slot(PtRenderer *r, int slot, void *hip_stream, void *rgba8_dev, void *f32_dev);
+int pt_last_slot(PtRenderer *r);
+
 /* hipEvent timing on the renderer's stream: begin/end bracket any number of
  * pt_render calls; elapsed waits for the end event. */
 int pt_timer_begin(PtRenderer *r);

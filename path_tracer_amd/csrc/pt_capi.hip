@@ -82,6 +82,7 @@ struct PtRenderer {
   hipStream_t ownStream = nullptr;
   hipStream_t stream = nullptr;      // ownStream, or the caller's (pt_set_stream)
   hipStream_t ownStream2 = nullptr;  // second frame in flight (slot 1)
+  hipStream_t stream2 = nullptr;     // ownStream2, or the caller's (pt_set_slot)
   hipEvent_t evBegin = nullptr, evEnd = nullptr, evCross = nullptr;
   // Two frames in flight (reference src/VulkanRenderer.cpp:1080-1100, MAX_FRAMES_IN_FLIGHT = 2): plain
   // pt_render calls alternate between two slots, each with its own stream, output frames and scratch,
@@ -118,7 +119,8 @@ struct PtRenderer {
   //   bits 5-7    unit-direction tolerance x 2^n        bits 8-15   sparse-mode lane threshold + 1
   //   bits 16-20  waves per workgroup, bits 21-23 workgroups per CU (0: chosen from the scene size)
   int tune = 0;
-  void *extRgba8 = nullptr, *extF32 = nullptr;
+  void *extRgba8 = nullptr, *extF32 = nullptr;   // caller-owned output of slot 0 (pt_set_output, pt_set_slot)
+  void *extRgba8B = nullptr, *extF32B = nullptr; // ... of slot 1 (pt_set_slot)
   bool floatOutput = true;
   int objectSource = 0;
 
@@ -148,8 +150,9 @@ int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {
 
 int ensure_outputs(PtRenderer *r, int slot) {
   size_t px = (size_t)r->width * (size_t)std::max(r->localRows, 1);
-  if (!r->extRgba8) PT_HIP_CHECK(r->dRgba8[slot].reserve(px * 4));
-  if (r->floatOutput && !r->extF32 && !r->extRgba8) PT_HIP_CHECK(r->dF32[slot].reserve(px * 16));
+  const void *ext8 = slot ? r->extRgba8B : r->extRgba8, *extF = slot ? r->extF32B : r->extF32;
+  if (!ext8) PT_HIP_CHECK(r->dRgba8[slot].reserve(px * 4));
+  if (r->floatOutput && !extF && !ext8) PT_HIP_CHECK(r->dF32[slot].reserve(px * 16));
   PT_HIP_CHECK(r->dScratch[slot].reserve(kScratchBytes));
   return PT_OK;
 }
@@ -157,14 +160,27 @@ int ensure_outputs(PtRenderer *r, int slot) {
 int sync_all(PtRenderer *r) {
   PT_HIP_CHECK(hipSetDevice(r->device));
   PT_HIP_CHECK(hipStreamSynchronize(r->stream));
-  if (r->ownStream2) PT_HIP_CHECK(hipStreamSynchronize(r->ownStream2));
+  if (r->stream2) PT_HIP_CHECK(hipStreamSynchronize(r->stream2));
   return PT_OK;
 }
 
 // Plain frames may alternate between the two slots unless something ties them to one
-// target: a caller's stream or output buffers, or the running sum of pt_render_samples.
+// target: a caller's stream or output buffers given for slot 0 only, or the running sum
+// of pt_render_samples.
 bool pipelined(const PtRenderer *r) {
-  return r->framesInFlight == 2 && r->stream == r->ownStream && !r->extRgba8 && !r->accumulate && r->ownStream2;
+  const bool streamsMatch = (r->stream == r->ownStream) == (r->stream2 == r->ownStream2);
+  const bool outputsMatch = (r->extRgba8 == nullptr) == (r->extRgba8B == nullptr);
+  return r->framesInFlight == 2 && streamsMatch && outputsMatch && !r->accumulate && r->stream2;
+}
+
+void *slot_rgba8(const PtRenderer *r, int slot) {
+  void *ext = slot ? r->extRgba8B : r->extRgba8;
+  return ext ? ext : r->dRgba8[slot].p;
+}
+void *slot_f32(const PtRenderer *r, int slot) {
+  void *ext8 = slot ? r->extRgba8B : r->extRgba8;
+  if (ext8) return slot ? r->extF32B : r->extF32;
+  return r->floatOutput ? r->dF32[slot].p : nullptr;
 }
 
 int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: the kernel's MODE (0 plain, 1 counting, 2 phase cycles)
@@ -176,7 +192,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     return fail(PT_ERR_INVALID, "pt_render: push-constant object counts exceed the uploaded scene");
   PT_HIP_CHECK(hipSetDevice(r->device));
   const int slot = (mode == 0 && pipelined(r)) ? (r->lastSlot ^ 1) : 0;
-  const hipStream_t stream = slot ? r->ownStream2 : r->stream;
+  const hipStream_t stream = slot ? r->stream2 : r->stream;
   int rc = ensure_outputs(r, slot);
   if (rc != PT_OK) return rc;
 
@@ -242,8 +258,8 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     P.brickX = (r->brickRes[0] + 7) / 8;
     P.brickY = (r->brickRes[1] + 7) / 8;
   }
-  P.outRgba8 = (uint32_t *)(r->extRgba8 ? r->extRgba8 : r->dRgba8[slot].p);
-  P.outF32 = (float4 *)(r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32[slot].p : nullptr));
+  P.outRgba8 = (uint32_t *)slot_rgba8(r, slot);
+  P.outF32 = (float4 *)slot_f32(r, slot);
   P.tileCounter = (unsigned int *)((char *)r->dScratch[slot].p + 512);
   P.counters = (unsigned long long *)((char *)r->dScratch[slot].p + 64);
 
@@ -372,6 +388,7 @@ int pt_create(int width, int height, int device, PtRenderer **out) {
   r->stream = r->ownStream;
   e = hipStreamCreateWithFlags(&r->ownStream2, hipStreamNonBlocking);
   if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+  r->stream2 = r->ownStream2;
   (void)hipEventCreate(&r->evBegin);
   (void)hipEventCreate(&r->evEnd);
   (void)hipEventCreateWithFlags(&r->evCross, hipEventDisableTiming);
@@ -385,7 +402,7 @@ void pt_destroy(PtRenderer *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
-  if (r->ownStream2) (void)hipStreamSynchronize(r->ownStream2);
+  if (r->stream2) (void)hipStreamSynchronize(r->stream2);
   DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8[0], &r->dRgba8[1], &r->dF32[0], &r->dF32[1],
                     &r->dScratch[0], &r->dScratch[1], &r->dTileOrder[0], &r->dTileOrder[1], &r->dBricks, &r->dAccum};
   for (DevBuf *b : bufs) b->release();
@@ -666,14 +683,14 @@ int pt_readback_rgba8(PtRenderer *r, uint8_t *dst, size_t dst_bytes) {
   if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_rgba8: destination too small");
   int rc = sync_all(r);
   if (rc != PT_OK) return rc;
-  const void *src = r->extRgba8 ? r->extRgba8 : r->dRgba8[r->lastSlot].p;
+  const void *src = slot_rgba8(r, r->lastSlot);
   PT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
 int pt_readback_f32(PtRenderer *r, float *dst, size_t dst_bytes) {
   if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_f32: null argument");
-  const void *src = r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32[r->lastSlot].p : nullptr);
+  const void *src = slot_f32(r, r->lastSlot);
   if (!src) return fail(PT_ERR_STATE, "pt_readback_f32: float output is disabled");
   size_t bytes = (size_t)r->width * r->localRows * 16;
   if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_f32: destination too small");
@@ -719,19 +736,37 @@ int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
   if (stride_rows < maxLocal) return fail(PT_ERR_INVALID, "pt_assemble_bands: stride_rows smaller than a rank's frame");
   PT_HIP_CHECK(hipSetDevice(r->device));
   dim3 block(256), grid((r->width + 255) / 256, r->height);
+  const hipStream_t astream = r->lastSlot ? r->stream2 : r->stream; // behind the frame just drawn
   if (elem_bytes == 4)
-    hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<uint32_t>), grid, block, 0, r->stream, (const uint32_t *)src,
+    hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<uint32_t>), grid, block, 0, astream, (const uint32_t *)src,
                        (uint32_t *)dst, r->width, r->height, band_rows, band_count, stride_rows);
   else
-    hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<float4>), grid, block, 0, r->stream, (const float4 *)src,
+    hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<float4>), grid, block, 0, astream, (const float4 *)src,
                        (float4 *)dst, r->width, r->height, band_rows, band_count, stride_rows);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
-void *pt_device_rgba8(PtRenderer *r) { return r ? (r->extRgba8 ? r->extRgba8 : r->dRgba8[r->lastSlot].p) : nullptr; }
-void *pt_device_f32(PtRenderer *r) {
-  return r ? (r->extRgba8 ? r->extF32 : (r->floatOutput ? r->dF32[r->lastSlot].p : nullptr)) : nullptr;
+void *pt_device_rgba8(PtRenderer *r) { return r ? slot_rgba8(r, r->lastSlot) : nullptr; }
+void *pt_device_f32(PtRenderer *r) { return r ? slot_f32(r, r->lastSlot) : nullptr; }
+int pt_last_slot(PtRenderer *r) { return r ? r->lastSlot : 0; }
+
+int pt_set_slot(PtRenderer *r, int slot, void *hip_stream, void *rgba8_dev, void *f32_dev) {
+  if (!r) return fail(PT_ERR_INVALID, "pt_set_slot: renderer is null");
+  if (slot != 0 && slot != 1) return fail(PT_ERR_INVALID, "pt_set_slot: slot is 0 or 1");
+  if (!rgba8_dev && f32_dev) return fail(PT_ERR_INVALID, "pt_set_slot: a float frame needs an rgba8 frame too");
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
+  if (slot == 0) {
+    r->stream = hip_stream ? (hipStream_t)hip_stream : r->ownStream;
+    r->extRgba8 = rgba8_dev;
+    r->extF32 = f32_dev;
+  } else {
+    r->stream2 = hip_stream ? (hipStream_t)hip_stream : r->ownStream2;
+    r->extRgba8B = rgba8_dev;
+    r->extF32B = f32_dev;
+  }
+  return PT_OK;
 }
 
 int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev) {
@@ -753,15 +788,15 @@ int pt_set_stream(PtRenderer *r, void *hip_stream) {
 int pt_timer_begin(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_timer_begin: renderer is null");
   // after everything queued so far on either slot; nothing queued later starts before it
-  PT_HIP_CHECK(hipEventRecord(r->evCross, r->ownStream2));
+  PT_HIP_CHECK(hipEventRecord(r->evCross, r->stream2));
   PT_HIP_CHECK(hipStreamWaitEvent(r->stream, r->evCross, 0));
   PT_HIP_CHECK(hipEventRecord(r->evBegin, r->stream));
-  PT_HIP_CHECK(hipStreamWaitEvent(r->ownStream2, r->evBegin, 0));
+  PT_HIP_CHECK(hipStreamWaitEvent(r->stream2, r->evBegin, 0));
   return PT_OK;
 }
 int pt_timer_end(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_timer_end: renderer is null");
-  PT_HIP_CHECK(hipEventRecord(r->evCross, r->ownStream2));
+  PT_HIP_CHECK(hipEventRecord(r->evCross, r->stream2));
   PT_HIP_CHECK(hipStreamWaitEvent(r->stream, r->evCross, 0));
   PT_HIP_CHECK(hipEventRecord(r->evEnd, r->stream));
   return PT_OK;

@@ -139,6 +139,12 @@ class HipRenderer:
     def setStream(self, stream_ptr: Optional[int]) -> None:
         _lib.check(self._lib.pt_set_stream(self._h, stream_ptr))
 
+    def setSlot(self, slot: int, stream_ptr: Optional[int], rgba8_ptr: Optional[int], f32_ptr: Optional[int] = None) -> None:
+        _lib.check(self._lib.pt_set_slot(self._h, slot, stream_ptr, rgba8_ptr, f32_ptr))
+
+    def lastSlot(self) -> int:
+        return self._lib.pt_last_slot(self._h)
+
     def setOption(self, option: int, value: int) -> None:
         _lib.check(self._lib.pt_set_option(self._h, option, value))
 

@@ -45,7 +45,7 @@ def main():
         sys.argv = ["pmc_summary", os.path.join(src, "trace_bench")]
         pmc_summary.main()
     with open(os.path.join(out, f"{rnd}_kernel_trace.txt"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras --frames-in-flight 1\n")
         f.write("# (default workload c2: 12 launches of pt_render_kernel<0,...> = 2 warm-up + 10 timed; <1,...> and <2,...> are the\n")
         f.write("#  instrumented, untimed counting and phase-timing launches)\n")
         f.write(buf.getvalue())
@@ -67,7 +67,7 @@ def main():
     text = "\n".join(l for l in buf.getvalue().splitlines()
                      if "rocclr" not in l and not (l.startswith("   ") and float(l.split()[-1]) < 1e4))
     with open(os.path.join(out, f"{rnd}_pmc.txt"), "w") as f:
-        f.write("# one rocprofv3 --pmc pass per block; bench.py --workload <wl> --steps 3 --warmup 1 --no-extras --no-cpu\n")
+        f.write("# one rocprofv3 --pmc pass per block; bench.py --workload <wl> --steps 3 --warmup 1 --no-extras --no-cpu --frames-in-flight 1\n")
         f.write("# FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; <1,...> and <2,...> are the instrumented (untimed) launch\n")
         f.write(text + "\n")
     traffic = {}
