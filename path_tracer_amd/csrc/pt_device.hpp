@@ -405,7 +405,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   int state = ST_IDLE;
   int outIdx = 0;
   int bounce = 0;
-  V3 curO = mk3(0, 0, 0), curD = mk3(0, 0, 1); // current path ray
+  V3 curD = mk3(0, 0, 1); // direction of the current path ray (its origin is rO while the path ray is in flight;
+                          // the next one's is written to rO when it is cast)
   float thr = 1.0f;                            // throughput (always a multiple of (1,1,1))
   V3 fin = mk3(0, 0, 0);                       // finalColor
   // ray in flight
@@ -486,13 +487,12 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         int x, ly, gy;
         if (tile_pixel_xy(L, fromNext ? nextTx : poolTx, fromNext ? nextTy : poolTy, p, x, ly, gy)) {
           // main() + createCameraRay (raytrace.comp:686-700, 121-140)
-          curO = ld3(L.cam);
           curD = camera_dir(L, x, gy);
           outIdx = ly * L.width + x;
           fin = mk3(0, 0, 0);
           thr = 1.0f;
           bounce = 0;
-          rO = curO; rD = curD; rTmax = kMaxDistance;
+          rO = ld3(L.cam); rD = curD; rTmax = kMaxDistance;
           state = ST_PATH;
           if (COUNT) cPath++;
         }
@@ -1094,8 +1094,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const float maxDist = hitAny ? bestT : kMaxDistance;
             // intersectBox (:519-532)
             const V3 invDir = mk3(1.0f / (curD.x + 1e-8f), 1.0f / (curD.y + 1e-8f), 1.0f / (curD.z + 1e-8f));
-            const V3 t0 = mul3(sub3(ld3(L.boxMin), curO), invDir);
-            const V3 t1 = mul3(sub3(ld3(L.boxMax), curO), invDir);
+            const V3 t0 = mul3(sub3(ld3(L.boxMin), rO), invDir);
+            const V3 t1 = mul3(sub3(ld3(L.boxMax), rO), invDir);
             const V3 tmn = mk3(glmin(t0.x, t1.x), glmin(t0.y, t1.y), glmin(t0.z, t1.z));
             const V3 tmx = mk3(glmax(t0.x, t1.x), glmax(t0.y, t1.y), glmax(t0.z, t1.z));
             float tNear = glmax(glmax(tmn.x, tmn.y), tmn.z);
@@ -1126,7 +1126,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                   return (float)vox[id];
                 };
                 while (t < tFar && stepCount < 500) {
-                  const V3 pos = madd3(curO, t, curD);
+                  const V3 pos = madd3(rO, t, curD);
                   const V3 rel = sub3(pos, vpos);
                   float density = 0.0f;
                   if (!(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z)) {
@@ -1176,7 +1176,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                   // sampleVolume (:485-517), nearest neighbour
-                  const V3 pos = madd3(curO, ts[u], curD);
+                  const V3 pos = madd3(rO, ts[u], curD);
                   const V3 rel = sub3(pos, vpos);
                   index[u] = -1;
                   if (u < n && !(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z)) {
@@ -1233,7 +1233,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             break;
           }
           // hit record of the winner
-          hitP = madd3(curO, bestT, curD);
+          hitP = madd3(rO, bestT, curD);
           if (bestIdx < Ns) { // hitSphere :161-165
             const float4 s = P.spheres[bestIdx];
             hitN = scale3(sub3(hitP, xyz(s)), 1.0f / s.w);
@@ -1242,7 +1242,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const int j = bestIdx - Ns;
             const float4 e0 = PT_ELL(j, 0), e1 = PT_ELL(j, 1), e2 = PT_ELL(j, 2), e3 = PT_ELL(j, 3);
             const V3 nq = xyz(e2), nq2 = xyz(e3);
-            const V3 oc = rotate_q(sub3(curO, xyz(e0)), nq, nq2, e0.w);
+            const V3 oc = rotate_q(sub3(rO, xyz(e0)), nq, nq2, e0.w);
             const V3 dir = rotate_q(curD, nq, nq2, e0.w);
             const V3 invR = xyz(e1);
             const V3 localPoint = madd3(oc, bestT, dir);
@@ -1256,7 +1256,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const float emissiveStrength = m2.y;
           if (emissiveStrength > 0.0f) // :637-639
             fin = add3(fin, scale3(scale3(surfaceColor, thr), emissiveStrength));
-          viewDir = normalize3(sub3(curO, hitP)); // :642
+          viewDir = normalize3(sub3(rO, hitP)); // :642
           // calculateLighting (:286-336)
           if (COUNT) cShaded++;
           const int shaderFunctionIndex = (int)m2.z;
@@ -1379,20 +1379,21 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const float transparency = m2.x;
           const float reflectivity = m1.w;
           bool cont = false;
+          V3 nextO = hitP;
           if (reflectivity > 0.01f) {
             const float surfaceOpacity = (1.0f - reflectivity) * (1.0f - transparency);
             fin = add3(fin, scale3(scale3(lit, thr), surfaceOpacity));
             thr = thr * reflectivity;
             const float kk = 2.0f * dot3(hitN, curD); // reflect(I,N) = I - 2 dot(N,I) N
             const V3 reflectDir = sub3(curD, scale3(hitN, kk));
-            curO = madd3(hitP, kEpsilon, hitN);
+            nextO = madd3(hitP, kEpsilon, hitN);
             curD = reflectDir;
             cont = true;
           } else if (transparency > 0.01f) {
             const float opacity = 1.0f - transparency;
             fin = add3(fin, scale3(scale3(lit, thr), opacity));
             thr = thr * transparency;
-            curO = madd3(hitP, kEpsilon, curD);
+            nextO = madd3(hitP, kEpsilon, curD);
             cont = true;
           } else {
             fin = add3(fin, scale3(lit, thr));
@@ -1402,7 +1403,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             bounce++;
             // loop head of traceIterative (:605-606)
             if (bounce < L.maxBounces && !(length3(mk3(thr, thr, thr)) < 0.001f)) {
-              rO = curO; rD = curD; rTmax = kMaxDistance;
+              rO = nextO; rD = curD; rTmax = kMaxDistance;
               state = ST_PATH;
               if (COUNT) cPath++;
               step = GO_EMITTED;
