@@ -281,7 +281,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   // <= 160 KiB: one 1024-thread group); otherwise read from global memory.
   // LDS per workgroup: the object image (if staged) + 1 KiB of queue/result scratch per wave.
   size_t objBytes = (size_t)r->imageFloat4s * sizeof(float4);
-  bool useLds = objBytes + 16 * 1024 + 1024 <= 160 * 1024; // + per-wave scratch + the copy of the frame constants
+  bool useLds = objBytes + 16 * 1024 + 2048 <= 160 * 1024; // + per-wave scratch + the copy of the frame constants + the b/255 table
   if (r->objectSource == 1 && !useLds)
     return fail(PT_ERR_INVALID, "pt_render: scene does not fit the 160 KiB LDS (PT_OPT_OBJECT_SOURCE=1)");
   if (r->objectSource == 2) useLds = false;
@@ -291,7 +291,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   else if (objBytes <= 64 * 1024) { threads = 512; blocksPerCu = 2; }   // 2 x (64 + 8) KiB
   else { threads = 1024; blocksPerCu = 1; }                             // 1 x (<=144 + 16) KiB
   if ((r->tune >> 16) & 0xff) { threads = 64 * ((r->tune >> 16) & 0x1f); blocksPerCu = std::max(1, (r->tune >> 21) & 7); }
-  size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15); // + the kernel's copy of the frame constants
+  size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15) + 1024; // + the kernel's copy of the frame constants + its b/255 table
   // Pooled tracing at the end of the frame pays when one pass over the spheres is long.
   {
     const size_t coopBytes = 64 + (size_t)threads * (6 * sizeof(float) + sizeof(unsigned long long)) +

@@ -371,14 +371,16 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   // Pooled tracing at the end of the frame (P.coop): control words, the pooled
   // rays (six arrays of blockDim.x floats) and one result slot per pooled ray.
   const int nThreads = (int)blockDim.x, nWaves = (int)(blockDim.x >> 6), waveInBlock = (int)(threadIdx.x >> 6);
-  char *const coopBase = (char *)paramsLds + ((sizeof(FrameParams) + 15) & ~(size_t)15);
+  // density of a voxel byte: the 256 quotients b / 255 (the IEEE division the shader does per sample), tabulated
+  float *const s_div255 = (float *)((char *)paramsLds + ((sizeof(FrameParams) + 15) & ~(size_t)15));
+  if (P.numVolumes > 0)
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_div255[i] = (float)i / 255.0f;
+  char *const coopBase = (char *)(s_div255 + 256);
   volatile int *const c_ctrl = (volatile int *)coopBase; // [0] switch, [1..2] pooled-ray count, [3..4] any ray left (by parity)
   float *const c_rays = (float *)(coopBase + 64);
   unsigned long long *const c_slot = (unsigned long long *)(coopBase + 64 + 6 * sizeof(float) * (size_t)nThreads);
-  if (P.coop) {
-    if (threadIdx.x < 8) c_ctrl[threadIdx.x] = 0;
-    __syncthreads();
-  }
+  if (P.coop && threadIdx.x < 8) c_ctrl[threadIdx.x] = 0;
+  __syncthreads(); // the table and the control words are in place
   bool coop = false; // wave-uniform: this wave has joined the pooled mode
   int coopPass = 0;
   const int lane = threadIdx.x & 63;
@@ -1198,7 +1200,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                   if (u < n) {
-                    const float density = (float)raw[u] / 255.0f;
+                    const float density = s_div255[raw[u]];
                     const float sampleAlpha = density * absorptionCoeff;
                     acc = __builtin_fmaf(1.0f - acc, sampleAlpha, acc);
                   }
