@@ -376,10 +376,13 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   if (P.numVolumes > 0)
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_div255[i] = (float)i / 255.0f;
   char *const coopBase = (char *)(s_div255 + 256);
-  volatile int *const c_ctrl = (volatile int *)coopBase; // [0] switch, [1..2] pooled-ray count, [3..4] any ray left (by parity)
+  int *const c_ctrl = (int *)coopBase; // [0] switch, [1..2] pooled-ray count, [3..4] any ray left, [5..6] exact-ray count (by parity)
+  // the control words are shared between waves: relaxed workgroup-scope atomics (LDS reads and writes that are not cached in registers)
+#define PT_CTRL_LOAD(i) __hip_atomic_load(&c_ctrl[(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define PT_CTRL_STORE(i, v) __hip_atomic_store(&c_ctrl[(i)], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
   float *const c_rays = (float *)(coopBase + 64);
   unsigned long long *const c_slot = (unsigned long long *)(coopBase + 64 + 6 * sizeof(float) * (size_t)nThreads);
-  if (P.coop && threadIdx.x < 8) c_ctrl[threadIdx.x] = 0;
+  if (P.coop && threadIdx.x < 8) PT_CTRL_STORE(threadIdx.x, 0);
   __syncthreads(); // the table and the control words are in place
   bool coop = false; // wave-uniform: this wave has joined the pooled mode
   int coopPass = 0;
@@ -514,8 +517,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     if (P.coop && !coop) {
       // The first wave of the workgroup that finds every ticket group drained asks
       // all of them to switch; each joins at the top of its next pass.
-      if (exhausted && lane == 0) c_ctrl[0] = 1;
-      if (__builtin_amdgcn_readfirstlane(c_ctrl[0]) != 0) {
+      if (exhausted && lane == 0) PT_CTRL_STORE(0, 1);
+      if (__builtin_amdgcn_readfirstlane(PT_CTRL_LOAD(0)) != 0) {
         coop = true;
         if (PHASES) tPooled = __builtin_amdgcn_s_memtime();
       }
@@ -747,11 +750,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const int par = coopPass & 1;
         ++coopPass;
         if (PHASES && waveInBlock == 0) nPooled++;
-        if (__ballot(live) != 0ull && lane == 0) c_ctrl[3 + par] = 1;
+        if (__ballot(live) != 0ull && lane == 0) PT_CTRL_STORE(3 + par, 1);
         const unsigned long long fm = __ballot(fastLane);
         int base = 0;
         if (fm != 0ull) {
-          if (lane == 0) base = atomicAdd((int *)&c_ctrl[1 + par], (int)__popcll(fm));
+          if (lane == 0) base = atomicAdd(&c_ctrl[1 + par], (int)__popcll(fm));
           base = __builtin_amdgcn_readfirstlane(base);
         }
         const int myPos = base + (int)__popcll(fm & laneMaskLt);
@@ -769,7 +772,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const unsigned long long xm = __ballot(want);
           int xb = 0;
           if (xm != 0ull) {
-            if (lane == 0) xb = atomicAdd((int *)&c_ctrl[5 + par], (int)__popcll(xm));
+            if (lane == 0) xb = atomicAdd(&c_ctrl[5 + par], (int)__popcll(xm));
             xb = __builtin_amdgcn_readfirstlane(xb);
           }
           myXPos = xb + (int)__popcll(xm & laneMaskLt);
@@ -781,9 +784,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           }
         }
         __syncthreads();
-        if (c_ctrl[3 + par] == 0) break; // no wave of the workgroup holds a ray: all leave together
-        if (threadIdx.x == 0) { c_ctrl[1 + (par ^ 1)] = 0; c_ctrl[3 + (par ^ 1)] = 0; c_ctrl[5 + (par ^ 1)] = 0; }
-        const int pooled = __builtin_amdgcn_readfirstlane(c_ctrl[1 + par]);
+        if (PT_CTRL_LOAD(3 + par) == 0) break; // no wave of the workgroup holds a ray: all leave together
+        if (threadIdx.x == 0) { PT_CTRL_STORE(1 + (par ^ 1), 0); PT_CTRL_STORE(3 + (par ^ 1), 0); PT_CTRL_STORE(5 + (par ^ 1), 0); }
+        const int pooled = __builtin_amdgcn_readfirstlane(PT_CTRL_LOAD(1 + par));
         const int batches = (pooled + 63) >> 6;
         if (PHASES && waveInBlock == 0) nPooledRays += (unsigned long long)pooled;
         if (batches > 0) {
@@ -801,7 +804,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           }
         }
         {
-          int xCount = __builtin_amdgcn_readfirstlane(c_ctrl[5 + par]);
+          int xCount = __builtin_amdgcn_readfirstlane(PT_CTRL_LOAD(5 + par));
           if (xCount > xCap) xCount = xCap;
           for (int e = waveInBlock; e < xCount; e += nWaves) {
             unsigned int roots = 0;
@@ -1471,6 +1474,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       if (lane == 0) { atomicAdd(&P.counters[10], (unsigned long long)g); atomicAdd(&P.counters[11], (unsigned long long)sl); }
     }
   }
+#undef PT_CTRL_LOAD
+#undef PT_CTRL_STORE
 #undef PT_IMG
 #undef PT_PAIR
 #undef PT_ELL
