@@ -26,297 +26,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pt_frame.hpp"
+
 namespace ptdev {
-
-constexpr float kMaxDistance = 1e10f; // raytrace.comp:94
-constexpr float kEpsilon = 0.001f;    // raytrace.comp:95
-constexpr int kTileDim = 8;           // pixels per tile edge: one 8x8 tile = one refill of a whole wave
-constexpr int kTilePixels = kTileDim * kTileDim;
-constexpr int kTicketGroups = 32;     // tile-ticket counters (power of two), one per group of workgroups
-constexpr int kTicketStride = 32;     // unsigned ints between two counters: one 128-byte line each
-
-struct FrameParams {
-  // camera basis, computed once per frame on the host with the same float
-  // operations createCameraRay uses per pixel (raytrace.comp:121-131)
-  float cam[3], fwd[3], right[3], up[3];
-  float aspect, fov;
-  float time;
-  float bgTop[3], bgBottom[3];
-  int width, height;     // full frame
-  int localRows;         // rows this renderer draws (compact band-major frame)
-  int bandRows, bandIndex, bandCount;
-  int numSpheres, numEllipsoids, numLights, numVolumes;
-  int numEmSpheres, numEmEllipsoids;
-  int maxBounces;
-  int tilesX, numTiles;
-  int sceneHuge;         // 1: some sphere has a non-finite or > 1e9 coordinate (no fast path)
-  float ellCenterMax;    // largest |centre coordinate| over the ellipsoids
-  float ellScale;        // bound on (1/radius) x (growth under rotateByQuaternion) over the ellipsoids; +inf: no deferral
-  // volume 0 (raytrace.comp:538-550); boxMin/boxMax/extent precomputed
-  float volPos[3], v0[3], v1[3], boxMin[3], boxMax[3], extent[3];
-  int res[3];
-  int volMaterial;
-  // Scene image: one contiguous block of float4, copied into LDS by every
-  // workgroup when it fits (offsets in float4 units):
-  //   [0)          sphere pairs, 2 float4 per pair (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1),
-  //                padded with copies of the last sphere to a multiple of 8 spheres
-  //   [offEll)     4 per ellipsoid: (c,qw) (1/radii,maxRadius) (-q.xyz,0) (-2q.xyz,0)
-  //   [offEllPair) 7 per pair of ellipsoids, every field as (first, second) of the pair:
-  //                (cx,cy) (cz,qw) (1/rx,1/ry) (1/rz,-qx) (-qy,-qz) (-2qx,-2qy) (-2qz,0); an odd
-  //                count is padded with a copy of the last ellipsoid
-  //   [offMat)     5 per material, as GPUMaterial
-  //   [offLight)   1 per light: (pos, intensity)
-  //   [offEmS)     3 per emissive sphere, ascending sphere index:
-  //                (c,r) (material colour, emissiveStrength) (shaderIndex, sphereIndex as int bits)
-  //   [offEmE)     3 per emissive ellipsoid: (c,maxRadius) (material colour, emissiveStrength) (ellipsoidIndex bits)
-  //   [offMatIdx)  uint16 material index per sphere, then per ellipsoid
-  const float4 *image;
-  int imageFloat4s;
-  int offEll, offEllPair, offMat, offLight, offEmS, offEmE, offMatIdx;
-  int matIdxEllBase;         // element offset of the ellipsoid part of the uint16 table
-  const float4 *spheres;     // (cx, cy, cz, r), one per sphere, global memory
-  const uint8_t *voxels;   // linear (x fastest, as uploaded) when brickX == 0, else bricked
-  int brickX, brickY;      // bricks per row and per slice of the bricked copy
-  uint32_t *outRgba8;
-  float4 *outF32;           // may be null
-  unsigned int *tileCounter;    // kTicketGroups counters, kTicketStride apart
-  unsigned long long *counters; // PT_CNT_COUNT slots, instrumented kernel only
-  // Optional drawing order (null: tiles are drawn in index order).  tileOrder holds
-  // three lists of numTiles entries each, one per cost class; classCount[c] is the
-  // length of list c.  Tickets run through class 2, then 1, then 0.
-  int *tileOrder;
-  unsigned int *classCount;
-  // Extensions without a counterpart in the reference (all zero: the reference's frame)
-  int volumeFilter; // 0 nearest neighbour (raytrace.comp:485-517), 1 trilinear
-  int sampleIndex;  // sub-pixel sample drawn by this launch; 0 = the reference's pixel-corner sample
-  int accumCount;   // with accum: number of samples in the sum after this launch
-  float4 *accum;    // running sum of the clamped samples per pixel, or null
-  int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
-  float unitTol;    // |dot(d,d) - 1| up to which a ray takes the dense sphere loop
-  int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
-  int tune;         // tuning switches of pt_set_option(100, ...), 0 in production; the kernel reads bit 0: no wave priorities
-};
-
-struct V3 { float x, y, z; };
-
-__device__ __forceinline__ V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
-__device__ __forceinline__ V3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
-__device__ __forceinline__ V3 add3(V3 a, V3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 mul3(V3 a, V3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ V3 scale3(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 div3s(V3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
-__device__ __forceinline__ V3 neg3(V3 a) { return mk3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ float dot3(V3 a, V3 b) {
-  return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
-}
-__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
-  return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
-             __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
-}
-__device__ __forceinline__ V3 madd3(V3 a, float s, V3 b) {
-  return mk3(__builtin_fmaf(s, b.x, a.x), __builtin_fmaf(s, b.y, a.y), __builtin_fmaf(s, b.z, a.z));
-}
-__device__ __forceinline__ float length3(V3 a) { return __builtin_sqrtf(dot3(a, a)); }
-__device__ __forceinline__ V3 normalize3(V3 a) {
-  float inv = 1.0f / length3(a);
-  return scale3(a, inv);
-}
-// GLSL max/min/clamp: max(x,y) = (x<y)?y:x ; min(x,y) = (y<x)?y:x (NaN in x propagates)
-__device__ __forceinline__ float glmax(float x, float y) { return (x < y) ? y : x; }
-__device__ __forceinline__ float glmin(float x, float y) { return (y < x) ? y : x; }
-__device__ __forceinline__ float glclamp(float x, float lo, float hi) { return glmin(glmax(x, lo), hi); }
-__device__ __forceinline__ float glfract(float x) { return x - __builtin_floorf(x); }
-
-// Two-wide float math: one v_pk_* instruction works on two spheres at once.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// Three-vectors of pairs: the same operations as V3, on two objects at once.
-struct P3 { f2 x, y, z; };
-__device__ __forceinline__ P3 mkp3(f2 x, f2 y, f2 z) { P3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ P3 splat3(V3 v) { return mkp3(mk2(v.x, v.x), mk2(v.y, v.y), mk2(v.z, v.z)); }
-__device__ __forceinline__ P3 add3p(P3 a, P3 b) { return mkp3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ P3 sub3p(P3 a, P3 b) { return mkp3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ P3 mul3p(P3 a, P3 b) { return mkp3(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ f2 dot3p(P3 a, P3 b) { return fma2(a.z, b.z, fma2(a.y, b.y, a.x * b.x)); }
-__device__ __forceinline__ P3 cross3p(P3 a, P3 b) {
-  return mkp3(fma2(a.y, b.z, -(a.z * b.y)), fma2(a.z, b.x, -(a.x * b.z)), fma2(a.x, b.y, -(a.y * b.x)));
-}
-__device__ __forceinline__ P3 madd3p(P3 a, f2 s, P3 b) { return mkp3(fma2(s, b.x, a.x), fma2(s, b.y, a.y), fma2(s, b.z, a.z)); }
-__device__ __forceinline__ P3 rotate_qp(P3 v, P3 q, P3 q2, f2 qw) {
-  P3 t = cross3p(q2, v);
-  return add3p(madd3p(v, qw, t), cross3p(q, t));
-}
-
-// rotateByQuaternion with q.xyz and 2*q.xyz supplied (raytrace.comp:99-108):
-// t = 2*cross(q, v) == cross(2q, v) exactly; v' = (v + qw*t) + cross(q, t)
-__device__ __forceinline__ V3 rotate_q(V3 v, V3 q, V3 q2, float qw) {
-  V3 t = cross3(q2, v);
-  return add3(madd3(v, qw, t), cross3(q, t));
-}
-
-// ---- surface shaders (compiled-in; index = position in the sorted path list + 1) ----
-
-// rainbow.glsl:1-8
-__device__ __forceinline__ float hue2rgb(float p, float q, float t) {
-  if (t < 0.0f) t += 1.0f;
-  if (t > 1.0f) t -= 1.0f;
-  if (t < 1.0f / 6.0f) return p + ((q - p) * 6.0f) * t;
-  if (t < 0.5f) return q;
-  if (t < 2.0f / 3.0f) return p + ((q - p) * (2.0f / 3.0f - t)) * 6.0f;
-  return p;
-}
-// rainbow.glsl:10-22
-__device__ __forceinline__ V3 hsl2rgb(float h, float s, float l) {
-  float H = glfract(h);
-  float S = glclamp(s, 0.0f, 1.0f);
-  float L = glclamp(l, 0.0f, 1.0f);
-  if (S == 0.0f) return mk3(L, L, L);
-  float q = (L < 0.5f) ? (L * (1.0f + S)) : ((L + S) - L * S);
-  float p = 2.0f * L - q;
-  return mk3(hue2rgb(p, q, H + 1.0f / 3.0f), hue2rgb(p, q, H), hue2rgb(p, q, H - 1.0f / 3.0f));
-}
-// rainbow.glsl:24-50 — returns result.emissive (result.color is 0)
-__device__ __forceinline__ V3 rainbow_emissive(V3 hitPoint, float emissiveStrength, float time) {
-  V3 sweepDir = normalize3(mk3(1.0f, 0.5f, 0.25f));
-  float phase = dot3(hitPoint, sweepDir) * 2.0f + time * 0.002f;
-  float cosVal = cosf(phase);
-  float hue = glfract(0.5f + 0.5f * cosVal);
-  return scale3(hsl2rgb(hue, 1.0f, 0.5f), emissiveStrength);
-}
-
-__device__ __forceinline__ uint32_t unorm8(float c) {
-  if (c != c) return 0u;
-  return (uint32_t)(int)__builtin_rintf(c * 255.0f);
-}
-
-// Pixel w (0..63) of the tile in tile column tx, tile row ty: x, local row ly (row of
-// the compact band-major frame) and full-frame row gy.  False when the pixel lies
-// outside the frame.
-__device__ __forceinline__ bool tile_pixel_xy(const FrameParams &P, int tx, int ty, int w, int &x, int &ly, int &gy) {
-  x = tx * kTileDim + (w & 7);
-  ly = ty * kTileDim + (w >> 3);
-  gy = ly;
-  if (P.bandCount > 1) {
-    const int band = ly / P.bandRows;
-    gy = (band * P.bandCount + P.bandIndex) * P.bandRows + (ly - band * P.bandRows);
-  }
-  return x < P.width && ly < P.localRows && gy < P.height;
-}
-__device__ __forceinline__ bool tile_pixel(const FrameParams &P, int tile, int w, int &x, int &ly, int &gy) {
-  return tile_pixel_xy(P, tile % P.tilesX, tile / P.tilesX, w, x, ly, gy);
-}
-
-// createCameraRay for pixel (x, gy) (raytrace.comp:121-140 with main()'s uv, :692-700)
-__device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) {
-  float fx = (float)x, fy = (float)gy;
-  if (P.sampleIndex != 0) {
-    // sub-pixel offset in [0,1)^2 from a counter-based hash of (pixel, sample)
-    uint32_t h = ((uint32_t)gy * (uint32_t)P.width + (uint32_t)x) * 0x9E3779B1u + (uint32_t)P.sampleIndex * 0x85EBCA77u;
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-    fx = fx + (float)(h & 0xFFFFu) / 65536.0f;
-    fy = fy + (float)(h >> 16) / 65536.0f;
-  }
-  float uvx = fx / (float)P.width;
-  float uvy = fy / (float)P.height;
-  uvy = 1.0f - uvy;
-  const float sx = ((uvx - 0.5f) * P.aspect) * P.fov;
-  const float sy = (uvy - 0.5f) * P.fov;
-  return normalize3(madd3(madd3(ld3(P.fwd), sx, ld3(P.right)), sy, ld3(P.up)));
-}
-
-// Drawing-order pass: one thread per tile looks at what the tile's centre pixel
-// sees first and files the tile under a cost class: 2 = a surface that bounces
-// the path on (long ray chains), 1 = any other surface or the volume box, 0 =
-// background.  The render kernel draws class 2 first and class 0 last, so the
-// pixels with the longest chains of rays are started early and the frame does
-// not end on them.  Only the ORDER of the tiles depends on this pass; what is
-// drawn for each pixel does not, so nothing here needs the render kernel's
-// exact arithmetic.
-template <bool STAGED>
-__global__ void __launch_bounds__(64) pt_tile_order_kernel(const FrameParams P) {
-  // STAGED: the spheres and ellipsoid records are copied to LDS first (the loops below
-  // would otherwise wait for one dependent global load per object)
-  extern __shared__ float4 s_objs[];
-  if (STAGED) {
-    for (int i = threadIdx.x; i < P.numSpheres; i += blockDim.x) s_objs[i] = P.spheres[i];
-    for (int i = threadIdx.x; i < 4 * P.numEllipsoids; i += blockDim.x) s_objs[P.numSpheres + i] = P.image[P.offEll + i];
-    __syncthreads();
-  }
-  const int tileRaw = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool inRange = tileRaw < P.numTiles;
-  const int tile = inRange ? tileRaw : P.numTiles - 1;
-  int x, ly, gy;
-  tile_pixel(P, tile, 4 * 8 + 4, x, ly, gy);
-  if (x >= P.width) x = P.width - 1;
-  if (gy >= P.height) gy = P.height - 1;
-  const V3 o = ld3(P.cam), d = camera_dir(P, x, gy);
-  // approximate square roots and reciprocals are good enough to rank tiles
-  float best = kMaxDistance;
-  int bestIdx = -1;
-  for (int i = 0; i < P.numSpheres; ++i) {
-    const float4 sp = STAGED ? s_objs[i] : P.spheres[i];
-    const V3 oc = sub3(o, xyz(sp));
-    const float hb = dot3(oc, d);
-    const float disc = hb * hb - (dot3(oc, oc) - sp.w * sp.w);
-    if (disc >= 0.0f) {
-      const float sq = __builtin_amdgcn_sqrtf(disc);
-      float t = -hb - sq;
-      if (t < kEpsilon) t = -hb + sq;
-      if (t >= kEpsilon && t <= best) { best = t; bestIdx = i; }
-    }
-  }
-  for (int j = 0; j < P.numEllipsoids; ++j) {
-    const float4 *er = STAGED ? s_objs + P.numSpheres + 4 * j : P.image + P.offEll + 4 * j;
-    const float4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
-    const V3 oc = mul3(rotate_q(sub3(o, xyz(e0)), xyz(e2), xyz(e3), e0.w), xyz(e1));
-    const V3 dir = mul3(rotate_q(d, xyz(e2), xyz(e3), e0.w), xyz(e1));
-    const float a = dot3(dir, dir), hb = dot3(oc, dir), c = dot3(oc, oc) - 1.0f;
-    const float disc = hb * hb - a * c;
-    if (disc >= 0.0f) {
-      const float sq = __builtin_amdgcn_sqrtf(disc), ia = __builtin_amdgcn_rcpf(a);
-      float t = (-hb - sq) * ia;
-      if (t < kEpsilon) t = (-hb + sq) * ia;
-      if (t >= kEpsilon && t <= best) { best = t; bestIdx = P.numSpheres + j; }
-    }
-  }
-  int cls = 0;
-  if (bestIdx >= 0) {
-    const unsigned short *mi = (const unsigned short *)(P.image + P.offMatIdx);
-    const int m = bestIdx < P.numSpheres ? mi[bestIdx] : mi[P.matIdxEllBase + (bestIdx - P.numSpheres)];
-    const float reflectivity = P.image[P.offMat + 5 * m + 1].w, transparency = P.image[P.offMat + 5 * m + 2].x;
-    cls = (P.maxBounces > 1 && (reflectivity > 0.01f || transparency > 0.01f)) ? 2 : 1;
-  }
-  if (cls == 0 && P.numVolumes > 0) {
-    // slab test against the volume box (raytrace.comp:519-533), any overlap in front of the eye
-    float t0 = 0.0f, t1 = kMaxDistance;
-    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-    for (int a = 0; a < 3; ++a) {
-      const float inv = 1.0f / dd[a];
-      const float ta = (P.boxMin[a] - oo[a]) * inv, tb = (P.boxMax[a] - oo[a]) * inv;
-      t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
-      t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
-    }
-    if (t0 <= t1) cls = 1;
-  }
-  // one atomic per wave and class, the three issued together by lanes 0..2; the
-  // lanes of a class take consecutive places behind its counter value
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const unsigned long long m0 = __ballot(inRange && cls == 0), m1 = __ballot(inRange && cls == 1),
-                           m2 = __ballot(inRange && cls == 2);
-  const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : m2);
-  unsigned int base = 0;
-  if (lane < 3 && mine != 0ull) base = atomicAdd(&P.classCount[lane], (unsigned int)__popcll(mine));
-  const unsigned int myBase = (unsigned int)__shfl((int)base, cls);
-  if (inRange) {
-    const unsigned long long m = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
-    P.tileOrder[cls * P.numTiles + (int)(myBase + (unsigned int)__popcll(m & lt))] = tile;
-  }
-}
 
 // Lane states: which kind of ray the lane has in flight.
 enum : int {
@@ -1491,37 +1203,4 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 // De-interleave the compact band-major frames of `bandCount` renderers into
 // one height x width frame.  Source frame of renderer p starts at
 // p * strideRows rows; elements are uint32 (rgba8) or float4.
-// Re-tile a linear x-fastest volume into 8x8x8 bricks (512 contiguous bytes
-// each; bricks x fastest).  Voxels outside the volume are written as 0.
-__global__ void __launch_bounds__(256) pt_brick_volume_kernel(const uint8_t *__restrict__ linear, uint8_t *__restrict__ bricks,
-                                                              int rx, int ry, int rz, int nbx, int nby, int nbz) {
-  const long long total = (long long)nbx * nby * nbz * 128; // 4 voxels per thread
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long brick = i >> 7;
-    const int in = (int)(i & 127) << 2; // first of 4 voxels along x
-    const int bx = (int)(brick % nbx), by = (int)((brick / nbx) % nby), bz = (int)(brick / ((long long)nbx * nby));
-    const int ix = (bx << 3) | (in & 7), iy = (by << 3) | ((in >> 3) & 7), iz = (bz << 3) | (in >> 6);
-    uint32_t w = 0;
-    if (iy < ry && iz < rz) {
-      const long long base = ix + (long long)iy * rx + (long long)iz * rx * ry;
-      for (int k = 0; k < 4; ++k)
-        if (ix + k < rx) w |= (uint32_t)linear[base + k] << (8 * k);
-    }
-    ((uint32_t *)bricks)[i] = w;
-  }
-}
-
-template <typename T>
-__global__ void pt_assemble_bands_kernel(const T *__restrict__ src, T *__restrict__ dst, int width, int height,
-                                         int bandRows, int bandCount, int strideRows) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int gy = blockIdx.y;
-  if (x >= width || gy >= height) return;
-  const int band = gy / bandRows;
-  const int owner = band % bandCount;
-  const int localBand = band / bandCount;
-  const int ly = localBand * bandRows + (gy - band * bandRows);
-  dst[(size_t)gy * width + x] = src[((size_t)owner * strideRows + ly) * width + x];
-}
-
 } // namespace ptdev
