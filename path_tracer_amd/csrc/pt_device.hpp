@@ -30,6 +30,10 @@
 
 namespace ptdev {
 
+// Where the dense sphere loop reads the sphere pairs from (compile-time choice per call site).
+struct ScalarTag { static constexpr bool value = true; };
+struct LdsTag { static constexpr bool value = false; };
+
 // Lane states: which kind of ray the lane has in flight.
 enum : int {
   ST_IDLE = 0,       // wants a pixel
@@ -55,8 +59,16 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     for (int i = threadIdx.x; i < P.imageFloat4s; i += blockDim.x) s_obj[i] = P.image[i];
     __syncthreads();
   }
-  const float4 *__restrict__ g_img = P.image;
-#define PT_IMG(i) (LDS_OBJECTS ? s_obj[(i)] : g_img[(i)])
+  // the scene image is read-only for the whole launch: through the constant address space, so that
+  // loads at wave-uniform addresses become scalar loads
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const v4f __attribute__((address_space(4))) *ConstImage;
+  const ConstImage g_img = (ConstImage)P.image;
+  auto ld_image = [&](int i) -> float4 {
+    const v4f v = g_img[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+  };
+#define PT_IMG(i) (LDS_OBJECTS ? s_obj[(i)] : ld_image(i))
 #define PT_PAIR(i) PT_IMG(i)
 #define PT_ELL(j, k) PT_IMG(P.offEll + 4 * (j) + (k))
 #define PT_ELLP(p, k) PT_IMG(P.offEllPair + 7 * (p) + (k))
@@ -66,7 +78,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #define PT_EME(e, k) PT_IMG(P.offEmE + 3 * (e) + (k))
 #define PT_MATIDX(i)                                                                        \
   ((int)(LDS_OBJECTS ? ((const unsigned short *)(s_obj + P.offMatIdx))[(i)]                 \
-                     : ((const unsigned short *)(g_img + P.offMatIdx))[(i)]))
+                     : ((const unsigned short __attribute__((address_space(4))) *)(g_img + P.offMatIdx))[(i)]))
 
   // Frame constants that are not needed in the intersection loops are read
   // from an LDS copy where they are used, instead of living in registers for
@@ -307,7 +319,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // The dense sphere pass for the 64 rays (ox..dz, one per lane) over sphere
       // groups [gBegin, gEnd), results into slot[lane].  A lane without a ray
       // passes one that can never produce a candidate (origin 4e9, direction 0).
-      auto denseSpheres = [&](const float ox, const float oy, const float oz, const float dx, const float dy,
+      // scalarTag: read the sphere pairs with scalar loads from the global copy of the image
+      // (the bulk of the frame: no LDS instruction in the loop, operands in SGPRs; the latency is
+      // hidden by the other waves) or from the LDS copy (pooled end of the frame, where few
+      // waves run and the short LDS latency counts).
+      auto denseSpheres = [&](auto scalarTag, const float ox, const float oy, const float oz, const float dx, const float dy,
                               const float dz, unsigned long long *slot, const int gBegin, const int gEnd) {
         int qHead = 0, qTail = 0; // ring of 128 entries, wave-uniform cursors
         // Evaluate n <= 64 queued (lane, sphere) candidates, one per lane.
@@ -371,8 +387,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     }                                                                            \
   }
         for (int g = gBegin; g < gEnd; ++g) {
-          const float4 a0 = PT_PAIR(8 * g), b0 = PT_PAIR(8 * g + 1), a1 = PT_PAIR(8 * g + 2), b1 = PT_PAIR(8 * g + 3);
-          const float4 a2 = PT_PAIR(8 * g + 4), b2 = PT_PAIR(8 * g + 5), a3 = PT_PAIR(8 * g + 6), b3 = PT_PAIR(8 * g + 7);
+#define PT_PAIR_AT(i) ((decltype(scalarTag)::value || !LDS_OBJECTS) ? ld_image(i) : s_obj[(i)])
+          const float4 a0 = PT_PAIR_AT(8 * g), b0 = PT_PAIR_AT(8 * g + 1), a1 = PT_PAIR_AT(8 * g + 2), b1 = PT_PAIR_AT(8 * g + 3);
+          const float4 a2 = PT_PAIR_AT(8 * g + 4), b2 = PT_PAIR_AT(8 * g + 5), a3 = PT_PAIR_AT(8 * g + 6), b3 = PT_PAIR_AT(8 * g + 7);
+#undef PT_PAIR_AT
           f2 d0, d1, d2, d3;
           PT_PAIR_DISC(a0, b0, d0)
           PT_PAIR_DISC(a1, b1, d1)
@@ -511,7 +529,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const float ox = has ? c_rays[at] : 4.0e9f, oy = has ? c_rays[nThreads + at] : 4.0e9f;
             const float oz = has ? c_rays[2 * nThreads + at] : 4.0e9f, dx = has ? c_rays[3 * nThreads + at] : 0.0f;
             const float dy = has ? c_rays[4 * nThreads + at] : 0.0f, dz = has ? c_rays[5 * nThreads + at] : 0.0f;
-            denseSpheres(ox, oy, oz, dx, dy, dz, c_slot + b * 64, (int)((long long)part * nGroups / split),
+            denseSpheres(LdsTag{}, ox, oy, oz, dx, dy, dz, c_slot + b * 64, (int)((long long)part * nGroups / split),
                          (int)((long long)(part + 1) * nGroups / split));
           }
         }
@@ -537,7 +555,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       } else if (__ballot(fastLane) != 0ull) {
-        denseSpheres(fastLane ? rO.x : 4.0e9f, fastLane ? rO.y : 4.0e9f, fastLane ? rO.z : 4.0e9f,
+        denseSpheres(ScalarTag{}, fastLane ? rO.x : 4.0e9f, fastLane ? rO.y : 4.0e9f, fastLane ? rO.z : 4.0e9f,
                      fastLane ? rD.x : 0.0f, fastLane ? rD.y : 0.0f, fastLane ? rD.z : 0.0f, w_slot, 0, nGroups);
       }
 

@@ -4,6 +4,7 @@ sys.path.insert(0, '.')
 from path_tracer_amd import scenes, HipRenderer
 name = sys.argv[1] if len(sys.argv) > 1 else 'c3'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+fixed = [tuple(int(x) for x in a.split(':')) for a in sys.argv[3:]]
 sc = {'c3': scenes.config3, 'c2': scenes.config2, 'c4': scenes.config4}[name]()
 pc = sc.push_constants()
 base = {}
@@ -11,7 +12,9 @@ for world in (1, 2, 4, 8):
     out = []
     for fif in (1, 2):
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-        r.setOption(1, 0); r.setOption(6, fif); r.setScene(sc)
+        r.setOption(1, 0); r.setOption(6, fif)
+        for k, val in fixed: r.setOption(k, val)
+        r.setScene(sc)
         if world > 1: r.setRowBands(16, 0, world)
         res = []
         for rep in range(3):
