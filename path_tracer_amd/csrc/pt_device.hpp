@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #define PT_IMG(i) (LDS_OBJECTS ? s_obj[(i)] : ld_image(i))
 #define PT_PAIR(i) PT_IMG(i)
 #define PT_ELL(j, k) PT_IMG(P.offEll + 4 * (j) + (k))
-#define PT_ELLP(p, k) PT_IMG(P.offEllPair + 7 * (p) + (k))
+#define PT_ELLP(p, k) ld_image(P.offEllPair + 7 * (p) + (k)) /* wave-uniform: scalar loads, like the sphere pairs */
 #define PT_MAT(m, k) PT_IMG(P.offMat + 5 * (m) + (k))
 #define PT_LIGHT(i) PT_IMG(P.offLight + (i))
 #define PT_EMS(e, k) PT_IMG(P.offEmS + 3 * (e) + (k))
