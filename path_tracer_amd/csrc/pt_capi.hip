@@ -115,7 +115,7 @@ struct PtRenderer {
   float ellCenterMax = 0.0f, ellScale = 0.0f; // see FrameParams
   bool sceneBounces = false;     // some object's material sends the path on (mirror or transparent)
   // Tuning switches for measurements (pt_set_option(100, bits); 0 = production, not part of the interface):
-  //   bit 0       no wave priorities            bit 4        no pooled end-of-frame tracing
+  //   bit 0       no wave priorities     bit 1  no fan-out of lighting rays     bit 4  no pooled end-of-frame tracing
   //   bits 5-7    unit-direction tolerance x 2^n        bits 8-15   sparse-mode lane threshold + 1
   //   bits 16-20  waves per workgroup, bits 21-23 workgroups per CU (0: chosen from the scene size)
   int tune = 0;
@@ -299,6 +299,11 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     const bool fits = ldsBytes + coopBytes <= 160 * 1024 / (size_t)blocksPerCu;
     P.coop = (pc->numSpheres >= 256 && fits && !(r->tune & 16)) ? 1 : 0;
     if (P.coop) ldsBytes += coopBytes;
+    // Fan-out of lighting rays at the end of the frame: where a hit casts several of them (and the pooled mode is off)
+    const size_t fanBytes = (size_t)(threads / 64) * ptdev::kFanBytes;
+    const bool fanFits = ldsBytes + fanBytes <= 160 * 1024 / (size_t)blocksPerCu;
+    P.fanOut = (!P.coop && pc->numLights + r->numEmSpheres + r->numEmEllipsoids >= 2 && fanFits && !(r->tune & 2)) ? 1 : 0;
+    if (P.fanOut) ldsBytes += fanBytes;
   }
   P.sceneHuge = r->sceneHuge ? 1 : 0;
   P.ellCenterMax = r->ellCenterMax;

@@ -41,7 +41,9 @@ enum : int {
   ST_LIGHT = 2,      // getShadowFactor for light k, Phong        (raytrace.comp:345)
   ST_TOON_LIGHT = 3, // getShadowFactor for light k, toon shader  (toon.glsl:19)
   ST_EM_SPHERE = 4,  // emissive-sphere occlusion ray             (raytrace.comp:431)
-  ST_EM_ELLIPSOID = 5 // emissive-ellipsoid occlusion ray         (raytrace.comp:469)
+  ST_EM_ELLIPSOID = 5, // emissive-ellipsoid occlusion ray        (raytrace.comp:469)
+  ST_JOB = 6,        // a shadow / occlusion ray cast on behalf of another lane (fan-out, see the kernel)
+  ST_WAIT = 7        // all of this lane's lighting rays are with other lanes; it casts none itself this pass
 };
 
 // MODE 0: the production kernel.  MODE 1: also counts rays, tests, roots and
@@ -147,6 +149,13 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   V3 lit = mk3(0, 0, 0);     // calculateLighting's finalColor / toon finalColor
   V3 pending = mk3(0, 0, 0); // contribution added if the occlusion ray is clear
   int k = 0;                 // light index or emissive-list cursor
+  // Fan-out at the end of the frame (P.fanOut): a lane in calculateLighting hands the shadow and
+  // occlusion rays that follow its current one to idle lanes of the wave, one record each in LDS.
+  int nRec = 0;              // records of this lane waiting for their results (one per round it took part in)
+  int jobPos = 0;            // ST_JOB: the record this lane traces
+  float *const f_rec = (float *)(coopBase + (size_t)waveInBlock * kFanBytes); // 13 fields x 64 records, field-major
+  unsigned long long *const f_roundMask = (unsigned long long *)(f_rec + 13 * 64); // owners that took part in round r
+  int *const f_roundBase = (int *)(f_roundMask + kFanRounds);                      // first record of round r
 
   unsigned int cRays = 0, cPath = 0, cLight = 0, cEmis = 0, cShaded = 0, cVoxel = 0;
   unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
@@ -272,7 +281,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     //    non-finite or huge coordinates, where NaNs make the shader's loop
     //    order-dependent, take the exact routine below instead.
     // ------------------------------------------------------------------
-    const bool live = state != ST_IDLE;
+    const bool live = state != ST_IDLE && state != ST_WAIT;
     float bestT = rTmax;
     int bestIdx = -1;
     bool qLane = false; // this lane's ellipsoid roots may be deferred (set below)
@@ -757,62 +766,185 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // 3. each live lane consumes its result and runs until it has emitted
     //    its next ray or finished its pixel
     // ------------------------------------------------------------------
+    // Labels of the per-lane coroutine.  `step` says where to resume.
+    enum { GO_PATH_RESULT, GO_NEXT_LIGHT, GO_NEXT_TOON_LIGHT, GO_NEXT_EM_SPHERE, GO_NEXT_EM_ELLIPSOID,
+           GO_AFTER_LIGHTING, GO_FINISH, GO_EMITTED };
+    const bool hitAny = bestIdx >= 0;
+
+    // What calculateLighting does with the outcome of one shadow / occlusion ray: `kind` is the
+    // lane state the ray was cast in, kk its light index, (dir, range) the ray, pend the
+    // contribution an emissive object makes if it is visible.
+    auto applyResult = [&](const int kind, const int kk, const bool occluded, const V3 dir, const float range, const V3 pend) {
+      if (occluded) return;
+      if (kind == ST_LIGHT) {
+        // raytrace.comp:348-363
+        const float4 Lt = PT_LIGHT(kk);
+        const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
+        const V3 surfaceColor = xyz(m0);
+        // lightDir and distance are the shadow ray's direction and range: the same
+        // expressions on the same operands (getShadowFactor :245-247 vs :349-351)
+        const float distance = range;
+        const V3 lightDir = dir;
+        const float attenuation = Lt.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
+        const float diffuseStrength = glmax(0.0f, dot3(hitN, lightDir));
+        const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseStrength), attenuation);
+        const V3 halfDir = normalize3(add3(lightDir, viewDir));
+        const float specularStrength = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
+        const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularStrength), attenuation);
+        lit = add3(lit, add3(diffuse, specular));
+      } else if (kind == ST_TOON_LIGHT) {
+        // toon.glsl:22-39
+        const float4 Lt = PT_LIGHT(kk);
+        const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
+        const V3 surfaceColor = xyz(m0);
+        const float distance = range; // as above (toon.glsl:19 vs :22-25)
+        const V3 lightDir = dir;
+        const float attenuation = Lt.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
+        const float diffuseRaw = glmax(0.0f, dot3(hitN, lightDir));
+        const float diffuseQuantized = diffuseRaw > 0.6f ? 1.0f : (diffuseRaw > 0.3f ? 0.5f : 0.0f);
+        const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseQuantized), attenuation);
+        const V3 halfDir = normalize3(add3(lightDir, viewDir));
+        const float specularRaw = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
+        const float specularQuantized = specularRaw > 0.8f ? 1.0f : 0.0f;
+        const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularQuantized), attenuation);
+        lit = add3(lit, add3(diffuse, specular));
+      } else { // ST_EM_SPHERE, ST_EM_ELLIPSOID: raytrace.comp:433-440, 471-477
+        lit = add3(lit, pend);
+      }
+    };
+
+    // The rays of calculateLighting that follow the one just cast: the next light
+    // (getShadowFactor :243-253), then the emissive spheres and ellipsoids that face the
+    // hit point (:367-480, over the precomputed emissive lists).  Leaves `step` at
+    // GO_EMITTED with the ray in (rO, rD, rTmax) or at the step after the lighting.
+    auto nextLightingRay = [&](int &step) {
+      if (step == GO_NEXT_LIGHT || step == GO_NEXT_TOON_LIGHT) do {
+        if (k < L.numLights) { // getShadowFactor (:243-253)
+          const float4 L = PT_LIGHT(k);
+          const V3 lightVec = sub3(xyz(L), hitP);
+          const float distToLight = length3(lightVec);
+          rO = hitP;
+          rD = div3s(lightVec, distToLight);
+          rTmax = distToLight;
+          state = (step == GO_NEXT_LIGHT) ? ST_LIGHT : ST_TOON_LIGHT;
+          if (COUNT) cLight++;
+          step = GO_EMITTED;
+        } else if (step == GO_NEXT_LIGHT) {
+          k = 0;
+          step = GO_NEXT_EM_SPHERE;
+        } else { // toon.glsl:42-47: result.color + result.emissive
+          const float4 m0 = PT_MAT(hitMat, 0);
+          const float4 m2 = PT_MAT(hitMat, 2);
+          V3 em = mk3(0, 0, 0);
+          if (m2.y > 0.0f) em = scale3(xyz(m0), m2.y);
+          lit = add3(lit, em);
+          step = GO_AFTER_LIGHTING;
+        }
+      } while (0);
+      if (step == GO_NEXT_EM_SPHERE) do { // raytrace.comp:367-443, over the precomputed emissive list
+        step = GO_NEXT_EM_ELLIPSOID;
+        while (k < L.numEmSpheres) {
+          const float4 s = PT_EMS(k, 0), sm = PT_EMS(k, 1), sx = PT_EMS(k, 2);
+          const int si = __float_as_int(sx.y);
+          if (si >= Ns) { k = L.numEmSpheres; break; }
+          float sphereEmissive = sm.w;
+          V3 emissiveColor = xyz(sm);
+          const V3 toSphere = sub3(xyz(s), hitP);
+          const float distToSphere = length3(toSphere);
+          const V3 dirToSphere = div3s(toSphere, distToSphere);
+          const int sphereShaderIndex = __float_as_int(sx.x);
+          bool skip = false;
+          if (sphereShaderIndex != 0) { // :377-414
+            const V3 approximateHitPoint = sub3(xyz(s), scale3(dirToSphere, s.w));
+            if (sphereShaderIndex == 1) {
+              emissiveColor = rainbow_emissive(approximateHitPoint, sphereEmissive, L.time);
+            } else if (sphereShaderIndex == 2) {
+              // toon keeps result.emissive = surfaceColor * emissiveStrength (toon.glsl:45-47);
+              // its light loop only feeds result.color, which this caller drops, so the
+              // shadow rays it would issue are elided (but still counted as issued)
+              emissiveColor = scale3(xyz(sm), sphereEmissive);
+              if (COUNT) { cLight += (unsigned int)L.numLights; cRays += (unsigned int)L.numLights; }
+            } else {
+              emissiveColor = mk3(0, 0, 0);
+            }
+            if (length3(emissiveColor) < 0.001f) skip = true;
+          }
+          if (!skip) {
+            const float alignment = dot3(hitN, dirToSphere);
+            if (alignment > 0.0f) {
+              rO = madd3(hitP, kEpsilon, hitN);
+              rD = dirToSphere;
+                  rTmax = (distToSphere - s.w) - kEpsilon;
+              const float attenuation =
+                  sphereEmissive / ((1.0f + 0.5f * distToSphere) + (0.1f * distToSphere) * distToSphere);
+              pending = scale3(scale3(emissiveColor, alignment), attenuation);
+              state = ST_EM_SPHERE;
+              if (COUNT) cEmis++;
+              step = GO_EMITTED;
+              break;
+            }
+          }
+          k++;
+        }
+        if (step != GO_EMITTED) k = 0;
+      } while (0);
+      if (step == GO_NEXT_EM_ELLIPSOID) do { // raytrace.comp:445-480
+        step = GO_AFTER_LIGHTING;
+        while (k < L.numEmEllipsoids) {
+          const float4 e0 = PT_EME(k, 0), em = PT_EME(k, 1), ex = PT_EME(k, 2);
+          const int ei = __float_as_int(ex.x);
+          if (ei >= Ne) { k = L.numEmEllipsoids; break; }
+          const V3 toE = sub3(xyz(e0), hitP);
+          const float distE = length3(toE);
+          const V3 dirE = div3s(toE, distE);
+          const float alignment = dot3(hitN, dirE);
+          if (alignment > 0.0f) {
+            rO = madd3(hitP, kEpsilon, hitN);
+            rD = dirE;
+              rTmax = (distE - e0.w) - kEpsilon;
+            const float attenuation = em.w / ((1.0f + 0.5f * distE) + (0.1f * distE) * distE);
+            pending = scale3(scale3(xyz(em), alignment), attenuation);
+            state = ST_EM_ELLIPSOID;
+            if (COUNT) cEmis++;
+            step = GO_EMITTED;
+            break;
+          }
+          k++;
+        }
+      } while (0);
+    };
+
+    if (P.fanOut) {
+      // helpers report, then go back to being idle
+      if (state == ST_JOB) {
+        f_rec[9 * 64 + jobPos] = hitAny ? 1.0f : 0.0f;
+        state = ST_IDLE;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
     if (state != ST_IDLE) {
-      const bool hitAny = bestIdx >= 0;
-      // Labels of the per-lane coroutine.  `step` says where to resume.
-      enum { GO_PATH_RESULT, GO_NEXT_LIGHT, GO_NEXT_TOON_LIGHT, GO_NEXT_EM_SPHERE, GO_NEXT_EM_ELLIPSOID,
-             GO_AFTER_LIGHTING, GO_FINISH, GO_EMITTED };
       int step;
+      // results of the rays this lane handed out last pass, in the order it would have cast them
+      for (int r = 0; r < nRec; ++r) {
+        const int pos = f_roundBase[r] + (int)__popcll(f_roundMask[r] & laneMaskLt);
+        const V3 dir = mk3(f_rec[2 * 64 + pos], f_rec[3 * 64 + pos], f_rec[4 * 64 + pos]);
+        const V3 pend = mk3(f_rec[6 * 64 + pos], f_rec[7 * 64 + pos], f_rec[8 * 64 + pos]);
+        applyResult(__float_as_int(f_rec[pos]), __float_as_int(f_rec[64 + pos]), f_rec[9 * 64 + pos] != 0.0f, dir,
+                    f_rec[5 * 64 + pos], pend);
+      }
+      nRec = 0;
       if (state == ST_PATH) {
         step = GO_PATH_RESULT;
-      } else if (state == ST_LIGHT) {
-        if (!hitAny) {
-          // raytrace.comp:348-363
-          const float4 L = PT_LIGHT(k);
-          const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
-          const V3 surfaceColor = xyz(m0);
-          // lightDir and distance are the shadow ray's direction and range: the same
-          // expressions on the same operands (getShadowFactor :245-247 vs :349-351)
-          const float distance = rTmax;
-          const V3 lightDir = rD;
-          const float attenuation = L.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
-          const float diffuseStrength = glmax(0.0f, dot3(hitN, lightDir));
-          const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseStrength), attenuation);
-          const V3 halfDir = normalize3(add3(lightDir, viewDir));
-          const float specularStrength = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
-          const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularStrength), attenuation);
-          lit = add3(lit, add3(diffuse, specular));
-        }
+      } else if (state == ST_WAIT) {
+        step = GO_AFTER_LIGHTING; // every lighting ray was with another lane
+      } else {
+        applyResult(state, k, hitAny, rD, rTmax, pending);
         k++;
-        step = GO_NEXT_LIGHT;
-      } else if (state == ST_TOON_LIGHT) {
-        if (!hitAny) {
-          // toon.glsl:22-39
-          const float4 L = PT_LIGHT(k);
-          const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
-          const V3 surfaceColor = xyz(m0);
-          const float distance = rTmax; // as above (toon.glsl:19 vs :22-25)
-          const V3 lightDir = rD;
-          const float attenuation = L.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
-          const float diffuseRaw = glmax(0.0f, dot3(hitN, lightDir));
-          const float diffuseQuantized = diffuseRaw > 0.6f ? 1.0f : (diffuseRaw > 0.3f ? 0.5f : 0.0f);
-          const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseQuantized), attenuation);
-          const V3 halfDir = normalize3(add3(lightDir, viewDir));
-          const float specularRaw = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
-          const float specularQuantized = specularRaw > 0.8f ? 1.0f : 0.0f;
-          const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularQuantized), attenuation);
-          lit = add3(lit, add3(diffuse, specular));
-        }
-        k++;
-        step = GO_NEXT_TOON_LIGHT;
-      } else if (state == ST_EM_SPHERE) {
-        if (!hitAny) lit = add3(lit, pending); // raytrace.comp:433-440
-        k++;
-        step = GO_NEXT_EM_SPHERE;
-      } else { // ST_EM_ELLIPSOID
-        if (!hitAny) lit = add3(lit, pending); // raytrace.comp:471-477
-        k++;
-        step = GO_NEXT_EM_ELLIPSOID;
+        step = state == ST_LIGHT ? GO_NEXT_LIGHT
+               : state == ST_TOON_LIGHT ? GO_NEXT_TOON_LIGHT
+               : state == ST_EM_SPHERE ? GO_NEXT_EM_SPHERE : GO_NEXT_EM_ELLIPSOID;
       }
 
       // The steps only ever lead forward (path result -> lights -> emissive spheres ->
@@ -1014,100 +1146,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             step = GO_NEXT_LIGHT;
           }
         } while (0);
-        if (step == GO_NEXT_LIGHT || step == GO_NEXT_TOON_LIGHT) do {
-          if (k < L.numLights) { // getShadowFactor (:243-253)
-            const float4 L = PT_LIGHT(k);
-            const V3 lightVec = sub3(xyz(L), hitP);
-            const float distToLight = length3(lightVec);
-            rO = hitP;
-            rD = div3s(lightVec, distToLight);
-            rTmax = distToLight;
-            state = (step == GO_NEXT_LIGHT) ? ST_LIGHT : ST_TOON_LIGHT;
-            if (COUNT) cLight++;
-            step = GO_EMITTED;
-          } else if (step == GO_NEXT_LIGHT) {
-            k = 0;
-            step = GO_NEXT_EM_SPHERE;
-          } else { // toon.glsl:42-47: result.color + result.emissive
-            const float4 m0 = PT_MAT(hitMat, 0);
-            const float4 m2 = PT_MAT(hitMat, 2);
-            V3 em = mk3(0, 0, 0);
-            if (m2.y > 0.0f) em = scale3(xyz(m0), m2.y);
-            lit = add3(lit, em);
-            step = GO_AFTER_LIGHTING;
-          }
-        } while (0);
-        if (step == GO_NEXT_EM_SPHERE) do { // raytrace.comp:367-443, over the precomputed emissive list
-          step = GO_NEXT_EM_ELLIPSOID;
-          while (k < L.numEmSpheres) {
-            const float4 s = PT_EMS(k, 0), sm = PT_EMS(k, 1), sx = PT_EMS(k, 2);
-            const int si = __float_as_int(sx.y);
-            if (si >= Ns) { k = L.numEmSpheres; break; }
-            float sphereEmissive = sm.w;
-            V3 emissiveColor = xyz(sm);
-            const V3 toSphere = sub3(xyz(s), hitP);
-            const float distToSphere = length3(toSphere);
-            const V3 dirToSphere = div3s(toSphere, distToSphere);
-            const int sphereShaderIndex = __float_as_int(sx.x);
-            bool skip = false;
-            if (sphereShaderIndex != 0) { // :377-414
-              const V3 approximateHitPoint = sub3(xyz(s), scale3(dirToSphere, s.w));
-              if (sphereShaderIndex == 1) {
-                emissiveColor = rainbow_emissive(approximateHitPoint, sphereEmissive, L.time);
-              } else if (sphereShaderIndex == 2) {
-                // toon keeps result.emissive = surfaceColor * emissiveStrength (toon.glsl:45-47);
-                // its light loop only feeds result.color, which this caller drops, so the
-                // shadow rays it would issue are elided (but still counted as issued)
-                emissiveColor = scale3(xyz(sm), sphereEmissive);
-                if (COUNT) { cLight += (unsigned int)L.numLights; cRays += (unsigned int)L.numLights; }
-              } else {
-                emissiveColor = mk3(0, 0, 0);
-              }
-              if (length3(emissiveColor) < 0.001f) skip = true;
-            }
-            if (!skip) {
-              const float alignment = dot3(hitN, dirToSphere);
-              if (alignment > 0.0f) {
-                rO = madd3(hitP, kEpsilon, hitN);
-                rD = dirToSphere;
-                    rTmax = (distToSphere - s.w) - kEpsilon;
-                const float attenuation =
-                    sphereEmissive / ((1.0f + 0.5f * distToSphere) + (0.1f * distToSphere) * distToSphere);
-                pending = scale3(scale3(emissiveColor, alignment), attenuation);
-                state = ST_EM_SPHERE;
-                if (COUNT) cEmis++;
-                step = GO_EMITTED;
-                break;
-              }
-            }
-            k++;
-          }
-          if (step != GO_EMITTED) k = 0;
-        } while (0);
-        if (step == GO_NEXT_EM_ELLIPSOID) do { // raytrace.comp:445-480
-          step = GO_AFTER_LIGHTING;
-          while (k < L.numEmEllipsoids) {
-            const float4 e0 = PT_EME(k, 0), em = PT_EME(k, 1), ex = PT_EME(k, 2);
-            const int ei = __float_as_int(ex.x);
-            if (ei >= Ne) { k = L.numEmEllipsoids; break; }
-            const V3 toE = sub3(xyz(e0), hitP);
-            const float distE = length3(toE);
-            const V3 dirE = div3s(toE, distE);
-            const float alignment = dot3(hitN, dirE);
-            if (alignment > 0.0f) {
-              rO = madd3(hitP, kEpsilon, hitN);
-              rD = dirE;
-                rTmax = (distE - e0.w) - kEpsilon;
-              const float attenuation = em.w / ((1.0f + 0.5f * distE) + (0.1f * distE) * distE);
-              pending = scale3(scale3(xyz(em), alignment), attenuation);
-              state = ST_EM_ELLIPSOID;
-              if (COUNT) cEmis++;
-              step = GO_EMITTED;
-              break;
-            }
-            k++;
-          }
-        } while (0);
+        nextLightingRay(step);
         if (step == GO_AFTER_LIGHTING) do { // raytrace.comp:645-671
           const float4 m1 = PT_MAT(hitMat, 1);
           const float4 m2 = PT_MAT(hitMat, 2);
@@ -1162,6 +1201,60 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           state = ST_IDLE;
           step = GO_EMITTED;
         } while (0);
+      }
+    }
+    // Fan-out.  Once the frame has run out of pixels, idle lanes are all that is left of most
+    // waves, while a lane inside calculateLighting still has up to numLights + emissive-object
+    // rays to cast one after the other.  Which rays those are does not depend on how the earlier
+    // ones end, so the lane runs ahead: per round it files its current ray as a record and
+    // moves on to its next one, as long as idle lanes remain to take the records; it traces the
+    // last ray itself.  Next pass the helpers report hit or miss and the lane applies the
+    // results in casting order, which keeps every sum in the order the shader forms it.
+    // (Toon lanes stay sequential: their last step adds to the sum before the results are in.)
+    if (P.fanOut && exhausted) {
+      const unsigned long long idleNow = __ballot(state == ST_IDLE);
+      bool gen = state == ST_LIGHT || state == ST_EM_SPHERE || state == ST_EM_ELLIPSOID;
+      const int helpers = (int)__popcll(idleNow);
+      if (helpers > 0 && __ballot(gen) != 0ull) {
+        int total = 0;
+        for (int round = 0; round < kFanRounds; ++round) {
+          const unsigned long long gm = __ballot(gen);
+          const int c = (int)__popcll(gm);
+          if (c == 0 || total + c > helpers) break;
+          if (gen) {
+            const int pos = total + (int)__popcll(gm & laneMaskLt);
+            f_rec[pos] = __int_as_float(state);
+            f_rec[64 + pos] = __int_as_float(k);
+            f_rec[2 * 64 + pos] = rD.x; f_rec[3 * 64 + pos] = rD.y; f_rec[4 * 64 + pos] = rD.z;
+            f_rec[5 * 64 + pos] = rTmax;
+            f_rec[6 * 64 + pos] = pending.x; f_rec[7 * 64 + pos] = pending.y; f_rec[8 * 64 + pos] = pending.z;
+            f_rec[10 * 64 + pos] = rO.x; f_rec[11 * 64 + pos] = rO.y; f_rec[12 * 64 + pos] = rO.z;
+            nRec++;
+          }
+          if (lane == 0) { f_roundMask[round] = gm; f_roundBase[round] = total; }
+          total += c;
+          if (gen) {
+            int step = state == ST_LIGHT ? GO_NEXT_LIGHT : (state == ST_EM_SPHERE ? GO_NEXT_EM_SPHERE : GO_NEXT_EM_ELLIPSOID);
+            k++;
+            nextLightingRay(step);
+            if (step != GO_EMITTED) { // no further ray: wait for the helpers, then go on after the lighting
+              gen = false;
+              state = ST_WAIT;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (state == ST_IDLE) {
+          const int q = (int)__popcll(idleNow & laneMaskLt);
+          if (q < total) {
+            rO = mk3(f_rec[10 * 64 + q], f_rec[11 * 64 + q], f_rec[12 * 64 + q]);
+            rD = mk3(f_rec[2 * 64 + q], f_rec[3 * 64 + q], f_rec[4 * 64 + q]);
+            rTmax = f_rec[5 * 64 + q];
+            jobPos = q;
+            state = ST_JOB;
+          }
+        }
       }
     }
     PT_PHASE(cycShade)

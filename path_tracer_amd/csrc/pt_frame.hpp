@@ -11,6 +11,8 @@ constexpr float kMaxDistance = 1e10f; // raytrace.comp:94
 constexpr float kEpsilon = 0.001f;    // raytrace.comp:95
 constexpr int kTileDim = 8;           // pixels per tile edge: one 8x8 tile = one refill of a whole wave
 constexpr int kTilePixels = kTileDim * kTileDim;
+constexpr int kFanRounds = 16;        // fan-out: rays handed out per lighting lane and pass, at most
+constexpr int kFanBytes = 13 * 64 * 4 + kFanRounds * 12; // fan-out records and round tables of one wave
 constexpr int kTicketGroups = 32;     // tile-ticket counters (power of two), one per group of workgroups
 constexpr int kTicketStride = 32;     // unsigned ints between two counters: one 128-byte line each
 
@@ -70,6 +72,7 @@ struct FrameParams {
   int sampleIndex;  // sub-pixel sample drawn by this launch; 0 = the reference's pixel-corner sample
   int accumCount;   // with accum: number of samples in the sum after this launch
   float4 *accum;    // running sum of the clamped samples per pixel, or null
+  int fanOut;       // 1: at the end of the frame lighting rays of one pixel are spread over idle lanes (not with coop)
   int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
   float unitTol;    // |dot(d,d) - 1| up to which a ray takes the dense sphere loop
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
