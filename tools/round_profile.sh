@@ -18,6 +18,7 @@ for wl in c2 c3 c4; do
     timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/trace_$wl -o t -- $B > $out/trace_$wl.log 2>&1 || { echo trace $wl failed; exit 1; }
   fi
   timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $out/pmc_sq_$wl -o p -- $B > $out/pmc_sq_$wl.log 2>&1 || { echo pmc sq $wl failed; exit 1; }
+  timeout -s KILL 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU -d $out/pmc_valu_$wl -o p -- $B > $out/pmc_valu_$wl.log 2>&1 || { echo pmc valu $wl failed; exit 1; }
   timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch_$wl -o p -- $B > $out/pmc_fetch_$wl.log 2>&1 || { echo pmc fetch $wl failed; exit 1; }
   timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write_$wl -o p -- $B > $out/pmc_write_$wl.log 2>&1 || { echo pmc write $wl failed; exit 1; }
 done
