@@ -93,7 +93,7 @@ class Runner:
             self.r.setRowBands(BAND_ROWS, rank, world)
             dev = f"cuda:{device}" if backend == "nccl" else "cpu"
             # one set of buffers per frame slot, so that a frame can be drawn while the previous one is gathered
-            for slot in range(2 if backend == "nccl" else 1):
+            for slot in range(max(frames_in_flight, 2) if backend == "nccl" else 1):
                 bg = BandGather(t, dist, scene.width, scene.height, rank, world, dev, band_rows=BAND_ROWS)
                 assert bg.local_rows == self.r.localRows()
                 self.bgs.append(bg)
@@ -253,11 +253,18 @@ def main():
                     help="collective backend for --gpus > 1 (gloo = host-memory rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the final frame against a single-GPU render")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
-                    help="2 (default): consecutive frames overlap on two streams, as in the reference; 1: one at a time")
+    ap.add_argument("--frames-in-flight", type=int, default=None, choices=range(1, 9),
+                    help="frames queued at once, each on a stream of its own (default: 2 on one GPU, as the reference's "
+                         "MAX_FRAMES_IN_FLIGHT; 4 when the frame is split over several GPUs, where a rank's share is short "
+                         "against its longest chain of dependent rays); 1: one at a time")
     ap.add_argument("--force-split", action="store_true",
                     help="testing: take the band-split + gather path even with one rank (exercises the RCCL plumbing on one GPU)")
     args = ap.parse_args()
+
+    # Libraries (RCCL's version banner, for one) write to stdout; the JSON line must be the only thing there.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -286,7 +293,7 @@ def main():
     n_gpus = world
 
     scene = build_scene(args.workload, args.scale)
-    fif = args.frames_in_flight
+    fif = args.frames_in_flight or (4 if (world > 1 or args.force_split) else 2)
     run = Runner(scene, rank, world, local_rank, torch_mod, dist, args.backend, split=(world > 1 or args.force_split),
                  frames_in_flight=fif)
     cnt = run.counters()
@@ -295,10 +302,10 @@ def main():
     dt, ev_ms = run.timed(args.steps, args.warmup)
     # The roofline leg: the same K frames one at a time, so that a launch's duration is that of a kernel running alone
     # (and is what a rocprofv3 trace of `--frames-in-flight 1` shows).
-    if fif == 2:
+    if fif >= 2:
         run.set_frames_in_flight(1)
         dt1, ev1_ms = run.timed(args.steps, 1)
-        run.set_frames_in_flight(2)
+        run.set_frames_in_flight(fif)
     else:
         dt1, ev1_ms = dt, ev_ms
     check = None
@@ -339,14 +346,14 @@ def main():
                                      measured_traffic(args.workload) if args.scale == 1.0 else None) if n_gpus == 1 else None,
         }
         result["frames_in_flight"] = fif
-        if fif == 2:
+        if fif >= 2:
             unit_count = float(cnt[6]) if args.workload == "c4" else rays
             result["one_frame_at_a_time"] = {
                 "ms_per_step": round(dt1 / args.steps * 1e3, 4), "value": round(unit_count / (dt1 / args.steps) / 1e6, 2),
                 "unit": unit,
                 "note": "same frames with PT_OPT_FRAMES_IN_FLIGHT = 1; the roofline object and the rocprofv3 summaries "
-                        "describe this mode (a kernel running alone); the headline has two frames in flight, the "
-                        "library's default, as the reference's MAX_FRAMES_IN_FLIGHT = 2"}
+                        "describe this mode (a kernel running alone); the headline has frames_in_flight frames queued at "
+                        "once (2 is the library's default, as the reference's MAX_FRAMES_IN_FLIGHT; 4 with a band split)"}
         if check is not None:
             result["config"]["gathered_frame_equals_single_gpu_frame"] = check
         if n_gpus > 1:
@@ -396,12 +403,14 @@ def main():
         sc = build_scene("c3")
         rr = Runner(sc, rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=fif)
         c = rr.counters()
-        d, e = rr.timed(5, 2)
+        k3 = 12
+        d, e = rr.timed(k3, fif)
         rr.close()
         if rank == 0:
-            result["workloads"] = {"c3": {"ms_per_frame": round(d / 5 * 1e3, 4), "Mrays_per_s": round(c[0] / (d / 5) / 1e6, 2),
-                                          "rays_per_frame": float(c[0]), "n_gpus": n_gpus,
-                                          "roofline": roofline_for(c / n_gpus, e / 5)}}
+            result["workloads"] = {"c3": {"ms_per_frame": round(d / k3 * 1e3, 4), "Mrays_per_s": round(c[0] / (d / k3) / 1e6, 2),
+                                          "rays_per_frame": float(c[0]), "n_gpus": n_gpus, "frames": k3,
+                                          "frames_in_flight": fif,
+                                          "roofline": roofline_for(c / n_gpus, e / k3)}}
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(scene)
@@ -411,8 +420,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -40,12 +40,15 @@ enum {
   PT_OPT_VOLUME_FILTER = 5, /* 0 (default): nearest-neighbour voxel sampling as in the
                                reference (shaders/raytrace.comp:485-517); 1: trilinear
                                (a quality mode of this library, no counterpart there)  */
-  PT_OPT_FRAMES_IN_FLIGHT = 6, /* 2 (default, the reference's MAX_FRAMES_IN_FLIGHT, src/VulkanRenderer.cpp
-                               :1080-1100): consecutive pt_render calls alternate between two
-                               streams and two sets of output frames, so a frame starts while the
-                               previous one finishes; pt_present waits for both, readback and
-                               pt_device_* show the most recent frame.  1: one frame at a time.
-                               A caller's stream or output buffers imply 1.                      */
+  PT_OPT_FRAMES_IN_FLIGHT = 6, /* n = 1 .. 8, default 2 (the reference's MAX_FRAMES_IN_FLIGHT,
+                               src/VulkanRenderer.cpp:1080-1100): consecutive pt_render calls go
+                               round n slots, each with its own stream and output frames, so a
+                               frame starts while the previous ones finish; pt_present waits for
+                               all, readback and pt_device_* show the most recent frame.  1: one
+                               frame at a time.  More than 2 pays where a frame is short against
+                               its longest chain of dependent rays (a rank's share of a frame
+                               split over many GPUs).  A caller's stream or output buffers given
+                               for slot 0 only imply 1.                                           */
   PT_OPT_TILE_ORDER = 3     /* 1: a short pass before each frame sorts the 8x8 tiles so
                                that those whose pixels cast the longest chains of rays
                                are drawn first; 0: index order; 2 (default): sorted
@@ -160,10 +163,10 @@ int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev);
  * renderer's own stream. */
 int pt_set_stream(PtRenderer *r, void *hip_stream);
 
-/* Both at once, per frame slot (0 or 1): stream (NULL: the renderer's own) and
+/* Both at once, per frame slot (0 .. 7): stream (NULL: the renderer's own) and
  * output buffers (NULL: internal) of the frames drawn in that slot.  With
- * PT_OPT_FRAMES_IN_FLIGHT = 2, consecutive pt_render calls alternate between the
- * slots when both are set up alike (both internal, or both with the caller's
+ * PT_OPT_FRAMES_IN_FLIGHT = n >= 2, consecutive pt_render calls go round slots
+ * 0 .. n-1 when these are set up alike (all internal, or all with the caller's
  * stream and buffers); pt_set_stream / pt_set_output configure slot 0 only and so
  * keep every frame in slot 0.  pt_last_slot tells which slot the most recent frame
  * went to; pt_assemble_bands runs on that slot's stream. */

@@ -79,14 +79,17 @@ struct PtRenderer {
   int width = 0, height = 0;
   int computeUnits = 0;
   char deviceName[256] = {0};
-  hipStream_t ownStream = nullptr;
-  hipStream_t stream = nullptr;      // ownStream, or the caller's (pt_set_stream)
-  hipStream_t ownStream2 = nullptr;  // second frame in flight (slot 1)
-  hipStream_t stream2 = nullptr;     // ownStream2, or the caller's (pt_set_slot)
-  hipEvent_t evBegin = nullptr, evEnd = nullptr, evCross = nullptr;
-  // Two frames in flight (reference src/VulkanRenderer.cpp:1080-1100, MAX_FRAMES_IN_FLIGHT = 2): plain
-  // pt_render calls alternate between two slots, each with its own stream, output frames and scratch,
-  // so the next frame fills the compute units the tail of the previous one leaves idle.
+  // Frames in flight (reference src/VulkanRenderer.cpp:1080-1100, MAX_FRAMES_IN_FLIGHT = 2): plain
+  // pt_render calls go round the slots, each with its own stream, output frames and scratch, so the
+  // next frames fill the compute units the tail of the previous ones leaves idle.  Two by default, as
+  // in the reference; up to kMaxSlots where a frame is short against its longest chain of dependent rays
+  // (a rank's share of a frame split over many GPUs).
+  static constexpr int kMaxSlots = 8;
+  hipStream_t ownStream[kMaxSlots] = {}; // created when the slot is first needed
+  hipStream_t stream[kMaxSlots] = {};    // ownStream[k], or the caller's (pt_set_stream for slot 0, pt_set_slot)
+  hipEvent_t evBegin = nullptr, evEnd = nullptr;
+  hipEvent_t evCross[kMaxSlots] = {};
+  int numSlots = 0;                  // slots with a stream: 0 .. numSlots-1
   int framesInFlight = 2;            // PT_OPT_FRAMES_IN_FLIGHT
   int lastSlot = 0;                  // slot of the most recent frame (what readback and pt_device_* show)
 
@@ -103,24 +106,26 @@ struct PtRenderer {
   int accumCount = 0;                        // samples in dAccum
   int sampleIndex = 0;                       // sample drawn by the next launch
   bool accumulate = false;
-  int imageFloat4s = 0, offEll = 0, offEllPair = 0, offMat = 0, offLight = 0, offEmS = 0, offEmE = 0, offMatIdx = 0, matIdxEllBase = 0;
+  int imageFloat4s = 0, offRadius = 0, offEll = 0, offEllPair = 0, offMat = 0, offLight = 0, offEmS = 0, offEmE = 0, offMatIdx = 0, matIdxEllBase = 0;
   bool voxelsUploaded = false;
   size_t voxelBytes = 0;
   PtGPUVolumetricData volume0{};
 
   // output
-  DevBuf dRgba8[2], dF32[2], dScratch[2]; // per slot; dScratch: see kScratchBytes
-  DevBuf dTileOrder[2];                   // 3 x numTiles tile indices (one list per cost class)
+  DevBuf dRgba8[kMaxSlots], dF32[kMaxSlots], dScratch[kMaxSlots]; // per slot; dScratch: see kScratchBytes
+  DevBuf dTileOrder[kMaxSlots];           // 3 x numTiles tile indices (one list per cost class)
   int tileOrder = 2;             // PT_OPT_TILE_ORDER: 0 off, 1 on, 2 decided per frame
   float ellCenterMax = 0.0f, ellScale = 0.0f; // see FrameParams
+  bool sphereFilter = false;     // the sphere pairs of the image carry the filter constant (FrameParams::sphereFilter)
   bool sceneBounces = false;     // some object's material sends the path on (mirror or transparent)
   // Tuning switches for measurements (pt_set_option(100, bits); 0 = production, not part of the interface):
   //   bit 0       no wave priorities     bit 1  no fan-out of lighting rays     bit 4  no pooled end-of-frame tracing
+  //   bit 2       discriminants in the dense sphere loop, no filter; bit 3: the filter whatever its margin costs
+  //               (both read by pt_update_scene)
   //   bits 5-7    unit-direction tolerance x 2^n        bits 8-15   sparse-mode lane threshold + 1
   //   bits 16-20  waves per workgroup, bits 21-23 workgroups per CU (0: chosen from the scene size)
   int tune = 0;
-  void *extRgba8 = nullptr, *extF32 = nullptr;   // caller-owned output of slot 0 (pt_set_output, pt_set_slot)
-  void *extRgba8B = nullptr, *extF32B = nullptr; // ... of slot 1 (pt_set_slot)
+  void *extRgba8[kMaxSlots] = {}, *extF32[kMaxSlots] = {}; // caller-owned output per slot (pt_set_output: slot 0, pt_set_slot)
   bool floatOutput = true;
   int objectSource = 0;
 
@@ -150,7 +155,7 @@ int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {
 
 int ensure_outputs(PtRenderer *r, int slot) {
   size_t px = (size_t)r->width * (size_t)std::max(r->localRows, 1);
-  const void *ext8 = slot ? r->extRgba8B : r->extRgba8, *extF = slot ? r->extF32B : r->extF32;
+  const void *ext8 = r->extRgba8[slot], *extF = r->extF32[slot];
   if (!ext8) PT_HIP_CHECK(r->dRgba8[slot].reserve(px * 4));
   if (r->floatOutput && !extF && !ext8) PT_HIP_CHECK(r->dF32[slot].reserve(px * 16));
   PT_HIP_CHECK(r->dScratch[slot].reserve(kScratchBytes));
@@ -159,27 +164,35 @@ int ensure_outputs(PtRenderer *r, int slot) {
 
 int sync_all(PtRenderer *r) {
   PT_HIP_CHECK(hipSetDevice(r->device));
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
-  if (r->stream2) PT_HIP_CHECK(hipStreamSynchronize(r->stream2));
+  for (int k = 0; k < r->numSlots; ++k) PT_HIP_CHECK(hipStreamSynchronize(r->stream[k]));
   return PT_OK;
 }
 
-// Plain frames may alternate between the two slots unless something ties them to one
-// target: a caller's stream or output buffers given for slot 0 only, or the running sum
-// of pt_render_samples.
-bool pipelined(const PtRenderer *r) {
-  const bool streamsMatch = (r->stream == r->ownStream) == (r->stream2 == r->ownStream2);
-  const bool outputsMatch = (r->extRgba8 == nullptr) == (r->extRgba8B == nullptr);
-  return r->framesInFlight == 2 && streamsMatch && outputsMatch && !r->accumulate && r->stream2;
+// Streams (and the events that tie them together for the timers) for slots 0 .. n-1.
+int ensure_slots(PtRenderer *r, int n) {
+  for (int k = r->numSlots; k < n; ++k) {
+    PT_HIP_CHECK(hipStreamCreateWithFlags(&r->ownStream[k], hipStreamNonBlocking));
+    if (!r->stream[k]) r->stream[k] = r->ownStream[k];
+    PT_HIP_CHECK(hipEventCreateWithFlags(&r->evCross[k], hipEventDisableTiming));
+    r->numSlots = k + 1;
+  }
+  return PT_OK;
 }
 
-void *slot_rgba8(const PtRenderer *r, int slot) {
-  void *ext = slot ? r->extRgba8B : r->extRgba8;
-  return ext ? ext : r->dRgba8[slot].p;
+// Plain frames may go round the slots unless something ties them to one target: a caller's
+// stream or output buffers given for some slots only, or the running sum of pt_render_samples.
+bool pipelined(const PtRenderer *r) {
+  if (r->framesInFlight < 2 || r->accumulate || r->numSlots < r->framesInFlight) return false;
+  for (int k = 1; k < r->framesInFlight; ++k) {
+    if ((r->stream[k] == r->ownStream[k]) != (r->stream[0] == r->ownStream[0])) return false;
+    if ((r->extRgba8[k] == nullptr) != (r->extRgba8[0] == nullptr)) return false;
+  }
+  return true;
 }
+
+void *slot_rgba8(const PtRenderer *r, int slot) { return r->extRgba8[slot] ? r->extRgba8[slot] : r->dRgba8[slot].p; }
 void *slot_f32(const PtRenderer *r, int slot) {
-  void *ext8 = slot ? r->extRgba8B : r->extRgba8;
-  if (ext8) return slot ? r->extF32B : r->extF32;
+  if (r->extRgba8[slot]) return r->extF32[slot];
   return r->floatOutput ? r->dF32[slot].p : nullptr;
 }
 
@@ -191,8 +204,8 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
       pc->numVolumes < 0 || pc->numVolumes > r->numVolumes)
     return fail(PT_ERR_INVALID, "pt_render: push-constant object counts exceed the uploaded scene");
   PT_HIP_CHECK(hipSetDevice(r->device));
-  const int slot = (mode == 0 && pipelined(r)) ? (r->lastSlot ^ 1) : 0;
-  const hipStream_t stream = slot ? r->stream2 : r->stream;
+  const int slot = (mode == 0 && pipelined(r)) ? (r->lastSlot + 1) % r->framesInFlight : 0;
+  const hipStream_t stream = r->stream[slot];
   int rc = ensure_outputs(r, slot);
   if (rc != PT_OK) return rc;
 
@@ -244,6 +257,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   P.spheres = (const float4 *)r->dSpheres.p;
   P.image = (const float4 *)r->dImage.p;
   P.imageFloat4s = r->imageFloat4s;
+  P.offRadius = r->offRadius;
   P.offEll = r->offEll;
   P.offEllPair = r->offEllPair;
   P.offMat = r->offMat;
@@ -317,6 +331,8 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   }
   P.tune = r->tune;
   P.unitTol = 0.25f * (float)(1 << ((r->tune >> 5) & 7)); // measured optimum on C3 (4096 spheres): broad, 0.06 .. 1
+  P.sphereFilter = r->sphereFilter ? 1 : 0;
+  if (P.sphereFilter) P.unitTol = std::min(P.unitTol, 0.25f); // the filter's error bound assumes |d|^2 <= 1.25
   {
     // Break-even between one dense pass (about 7.5 instructions per sphere, whatever the number
     // of rays) and the exact routine (about 0.31 per sphere + 150, per ray).
@@ -388,16 +404,11 @@ int pt_create(int width, int height, int device, PtRenderer **out) {
   if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)); }
   r->computeUnits = prop.multiProcessorCount;
   std::snprintf(r->deviceName, sizeof r->deviceName, "%s (%s)", prop.name, prop.gcnArchName);
-  e = hipStreamCreateWithFlags(&r->ownStream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-  r->stream = r->ownStream;
-  e = hipStreamCreateWithFlags(&r->ownStream2, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete r; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-  r->stream2 = r->ownStream2;
+  int rc = ensure_slots(r, r->framesInFlight);
+  if (rc != PT_OK) { pt_destroy(r); return rc; }
   (void)hipEventCreate(&r->evBegin);
   (void)hipEventCreate(&r->evEnd);
-  (void)hipEventCreateWithFlags(&r->evCross, hipEventDisableTiming);
-  int rc = ensure_outputs(r, 0);
+  rc = ensure_outputs(r, 0);
   if (rc != PT_OK) { pt_destroy(r); return rc; }
   *out = r;
   return PT_OK;
@@ -406,16 +417,17 @@ int pt_create(int width, int height, int device, PtRenderer **out) {
 void pt_destroy(PtRenderer *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  if (r->stream) (void)hipStreamSynchronize(r->stream);
-  if (r->stream2) (void)hipStreamSynchronize(r->stream2);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dRgba8[0], &r->dRgba8[1], &r->dF32[0], &r->dF32[1],
-                    &r->dScratch[0], &r->dScratch[1], &r->dTileOrder[0], &r->dTileOrder[1], &r->dBricks, &r->dAccum};
+  for (int k = 0; k < r->numSlots; ++k)
+    if (r->stream[k]) (void)hipStreamSynchronize(r->stream[k]);
+  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dBricks, &r->dAccum};
   for (DevBuf *b : bufs) b->release();
+  for (int k = 0; k < PtRenderer::kMaxSlots; ++k) {
+    r->dRgba8[k].release(); r->dF32[k].release(); r->dScratch[k].release(); r->dTileOrder[k].release();
+    if (r->evCross[k]) (void)hipEventDestroy(r->evCross[k]);
+    if (r->ownStream[k]) (void)hipStreamDestroy(r->ownStream[k]);
+  }
   if (r->evBegin) (void)hipEventDestroy(r->evBegin);
   if (r->evEnd) (void)hipEventDestroy(r->evEnd);
-  if (r->evCross) (void)hipEventDestroy(r->evCross);
-  if (r->ownStream) (void)hipStreamDestroy(r->ownStream);
-  if (r->ownStream2) (void)hipStreamDestroy(r->ownStream2);
   delete r;
 }
 
@@ -463,17 +475,40 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     for (float v : {hs[i].x, hs[i].y, hs[i].z, hs[i].w})
       if (!(std::fabs(v) <= 1.0e9f)) sceneHuge = true;
   }
+  // The dense loop's filter (FrameParams::sphereFilter): k = |c|^2 - r^2 - 2^-17 (|c|^2 + r^2) - 1e-30, rounded down.
+  // Its margin widens every sphere by about 2^-17 (|o|^2 + |c|^2) in r^2; it is used when that is small
+  // next to r^2 for the scene's spheres on average (taking |o| ~ |c|), else the loop computes discriminants.
+  std::vector<float> hk((size_t)num_spheres);
+  bool sphereFilter = false;
+  if (!sceneHuge && num_spheres > 0 && !(r->tune & 4)) {
+    double widen = 0.0;
+    for (int i = 0; i < num_spheres; ++i) {
+      const double c2 = (double)hs[i].x * hs[i].x + (double)hs[i].y * hs[i].y + (double)hs[i].z * hs[i].z;
+      const double r2 = (double)hs[i].w * hs[i].w;
+      const double margin = 0x1p-17 * (c2 + r2) + 1.0e-30;
+      hk[i] = std::nextafterf((float)(c2 - r2 - margin), -INFINITY);
+      widen += std::min(r2 > 0.0 ? 0x1p-17 * (2.0 * c2 + r2) / r2 : 4.0, 4.0);
+    }
+    sphereFilter = widen / num_spheres <= 0.5 || (r->tune & 8);
+  }
   std::vector<float4> img;
   // The intersection loop reads spheres two at a time:
-  //   (cx0, cx1, cy0, cy1) (cz0, cz1, r0, r1)
+  //   (cx0, cx1, cy0, cy1) (cz0, cz1, w0, w1),  w = radius or the filter's k
   // padded with copies of the last sphere to whole groups of eight (the copies
   // can never win: their index is >= the sphere count).
   const int nGroups = (num_spheres + 7) / 8;
   for (int p = 0; p < nGroups * 4; ++p) {
-    const float4 &s0 = hs[std::min(2 * p, num_spheres - 1)];
-    const float4 &s1 = hs[std::min(2 * p + 1, num_spheres - 1)];
+    const int i0 = std::min(2 * p, num_spheres - 1), i1 = std::min(2 * p + 1, num_spheres - 1);
+    const float4 &s0 = hs[i0];
+    const float4 &s1 = hs[i1];
     img.push_back(make_float4(s0.x, s1.x, s0.y, s1.y));
-    img.push_back(make_float4(s0.z, s1.z, s0.w, s1.w));
+    img.push_back(make_float4(s0.z, s1.z, sphereFilter ? hk[i0] : s0.w, sphereFilter ? hk[i1] : s1.w));
+  }
+  // radius per sphere, for the evaluation of the candidates
+  const int offRadius = (int)img.size();
+  for (int i = 0; i < num_spheres; i += 4) {
+    auto rad = [&](int j) { return j < num_spheres ? hs[j].w : 0.0f; };
+    img.push_back(make_float4(rad(i), rad(i + 1), rad(i + 2), rad(i + 3)));
   }
   // Ellipsoids: centre + qw, 1/radii + max radius, -q.xyz, -2 q.xyz.  1/radii is
   // the same IEEE division hitEllipsoid does per test (reference
@@ -546,8 +581,8 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   }
 
   int rc;
-  if ((rc = upload(r->dSpheres, hs, r->stream)) != PT_OK) return rc;
-  if ((rc = upload(r->dImage, img, r->stream)) != PT_OK) return rc;
+  if ((rc = upload(r->dSpheres, hs, r->stream[0])) != PT_OK) return rc;
+  if ((rc = upload(r->dImage, img, r->stream[0])) != PT_OK) return rc;
 
   if (num_volumes > 0) {
     r->volume0 = volumes[0];
@@ -556,15 +591,15 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
       // Uploaded once (reference src/VulkanRenderer.cpp:961-987).  Voxels the
       // file did not supply read as 0.
       PT_HIP_CHECK(r->dVoxels.reserve(need + 16));
-      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream));
-      PT_HIP_CHECK(hipMemcpyAsync(r->dVoxels.p, voxels, std::min(need, voxel_bytes), hipMemcpyHostToDevice, r->stream));
+      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream[0]));
+      PT_HIP_CHECK(hipMemcpyAsync(r->dVoxels.p, voxels, std::min(need, voxel_bytes), hipMemcpyHostToDevice, r->stream[0]));
       r->voxelsUploaded = true;
       r->voxelBytes = need;
       r->brickRes[0] = 0; // rebuild the bricked copy
     } else if (!r->voxelsUploaded || r->voxelBytes < need) {
       // A volume without data marches through zeros.
       PT_HIP_CHECK(r->dVoxels.reserve(need + 16));
-      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream));
+      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream[0]));
       r->voxelBytes = need;
       r->brickRes[0] = 0;
     }
@@ -579,7 +614,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
       if (brickBytes <= 0x7fffffffll) { // the march indexes with 32-bit integers
         PT_HIP_CHECK(r->dBricks.reserve((size_t)brickBytes));
         const int grid = (int)std::min<long long>((brickBytes / 4 + 255) / 256, 65536);
-        hipLaunchKernelGGL(ptdev::pt_brick_volume_kernel, dim3(grid), dim3(256), 0, r->stream, (const uint8_t *)r->dVoxels.p,
+        hipLaunchKernelGGL(ptdev::pt_brick_volume_kernel, dim3(grid), dim3(256), 0, r->stream[0], (const uint8_t *)r->dVoxels.p,
                            (uint8_t *)r->dBricks.p, v.resolution_x, v.resolution_y, v.resolution_z, nbx, nby, nbz);
         PT_HIP_CHECK(hipGetLastError());
         r->brickRes[0] = v.resolution_x; r->brickRes[1] = v.resolution_y; r->brickRes[2] = v.resolution_z;
@@ -589,7 +624,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     }
   }
   // The host vectors die at return: finish the copies first.
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream[0]));
 
   r->sceneHuge = sceneHuge;
   {
@@ -625,6 +660,8 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
   r->numEmSpheres = nEmS;
   r->numEmEllipsoids = nEmE;
   r->imageFloat4s = (int)img.size();
+  r->offRadius = offRadius;
+  r->sphereFilter = sphereFilter;
   r->offEll = offEll;
   r->offEllPair = offEllPair;
   r->offMat = offMat;
@@ -665,12 +702,12 @@ int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counte
   if (!counters) return fail(PT_ERR_INVALID, "pt_render_counted: counters is null");
   int rc = launch_frame(r, pc, 1);
   if (rc != PT_OK) return rc;
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream[0]));
   PT_HIP_CHECK(hipMemcpy(counters, (char *)r->dScratch[0].p + 64, PT_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
   // the per-phase cycle sums come from a second frame drawn by the production code with timers only
   rc = launch_frame(r, pc, 2);
   if (rc != PT_OK) return rc;
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream[0]));
   uint64_t cyc[PT_CNT_COUNT];
   PT_HIP_CHECK(hipMemcpy(cyc, (char *)r->dScratch[0].p + 64, sizeof cyc, hipMemcpyDeviceToHost));
   for (int i = PT_CNT_CYC_REFILL; i < PT_CNT_COUNT; ++i) counters[i] = cyc[i];
@@ -741,7 +778,7 @@ int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
   if (stride_rows < maxLocal) return fail(PT_ERR_INVALID, "pt_assemble_bands: stride_rows smaller than a rank's frame");
   PT_HIP_CHECK(hipSetDevice(r->device));
   dim3 block(256), grid((r->width + 255) / 256, r->height);
-  const hipStream_t astream = r->lastSlot ? r->stream2 : r->stream; // behind the frame just drawn
+  const hipStream_t astream = r->stream[r->lastSlot]; // behind the frame just drawn
   if (elem_bytes == 4)
     hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<uint32_t>), grid, block, 0, astream, (const uint32_t *)src,
                        (uint32_t *)dst, r->width, r->height, band_rows, band_count, stride_rows);
@@ -758,27 +795,22 @@ int pt_last_slot(PtRenderer *r) { return r ? r->lastSlot : 0; }
 
 int pt_set_slot(PtRenderer *r, int slot, void *hip_stream, void *rgba8_dev, void *f32_dev) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_slot: renderer is null");
-  if (slot != 0 && slot != 1) return fail(PT_ERR_INVALID, "pt_set_slot: slot is 0 or 1");
+  if (slot < 0 || slot >= PtRenderer::kMaxSlots) return fail(PT_ERR_INVALID, "pt_set_slot: slot is 0 .. 7");
   if (!rgba8_dev && f32_dev) return fail(PT_ERR_INVALID, "pt_set_slot: a float frame needs an rgba8 frame too");
   int rc = sync_all(r);
   if (rc != PT_OK) return rc;
-  if (slot == 0) {
-    r->stream = hip_stream ? (hipStream_t)hip_stream : r->ownStream;
-    r->extRgba8 = rgba8_dev;
-    r->extF32 = f32_dev;
-  } else {
-    r->stream2 = hip_stream ? (hipStream_t)hip_stream : r->ownStream2;
-    r->extRgba8B = rgba8_dev;
-    r->extF32B = f32_dev;
-  }
+  if ((rc = ensure_slots(r, slot + 1)) != PT_OK) return rc;
+  r->stream[slot] = hip_stream ? (hipStream_t)hip_stream : r->ownStream[slot];
+  r->extRgba8[slot] = rgba8_dev;
+  r->extF32[slot] = f32_dev;
   return PT_OK;
 }
 
 int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_output: renderer is null");
   if (!rgba8_dev && f32_dev) return fail(PT_ERR_INVALID, "pt_set_output: a float frame needs an rgba8 frame too");
-  r->extRgba8 = rgba8_dev;
-  r->extF32 = f32_dev;
+  r->extRgba8[0] = rgba8_dev;
+  r->extF32[0] = f32_dev;
   return PT_OK;
 }
 
@@ -786,24 +818,28 @@ int pt_set_stream(PtRenderer *r, void *hip_stream) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_stream: renderer is null");
   int rc = sync_all(r);
   if (rc != PT_OK) return rc;
-  r->stream = hip_stream ? (hipStream_t)hip_stream : r->ownStream;
+  r->stream[0] = hip_stream ? (hipStream_t)hip_stream : r->ownStream[0];
   return PT_OK;
 }
 
 int pt_timer_begin(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_timer_begin: renderer is null");
-  // after everything queued so far on either slot; nothing queued later starts before it
-  PT_HIP_CHECK(hipEventRecord(r->evCross, r->stream2));
-  PT_HIP_CHECK(hipStreamWaitEvent(r->stream, r->evCross, 0));
-  PT_HIP_CHECK(hipEventRecord(r->evBegin, r->stream));
-  PT_HIP_CHECK(hipStreamWaitEvent(r->stream2, r->evBegin, 0));
+  // after everything queued so far on any slot; nothing queued later starts before it
+  for (int k = 1; k < r->numSlots; ++k) {
+    PT_HIP_CHECK(hipEventRecord(r->evCross[k], r->stream[k]));
+    PT_HIP_CHECK(hipStreamWaitEvent(r->stream[0], r->evCross[k], 0));
+  }
+  PT_HIP_CHECK(hipEventRecord(r->evBegin, r->stream[0]));
+  for (int k = 1; k < r->numSlots; ++k) PT_HIP_CHECK(hipStreamWaitEvent(r->stream[k], r->evBegin, 0));
   return PT_OK;
 }
 int pt_timer_end(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_timer_end: renderer is null");
-  PT_HIP_CHECK(hipEventRecord(r->evCross, r->stream2));
-  PT_HIP_CHECK(hipStreamWaitEvent(r->stream, r->evCross, 0));
-  PT_HIP_CHECK(hipEventRecord(r->evEnd, r->stream));
+  for (int k = 1; k < r->numSlots; ++k) {
+    PT_HIP_CHECK(hipEventRecord(r->evCross[k], r->stream[k]));
+    PT_HIP_CHECK(hipStreamWaitEvent(r->stream[0], r->evCross[k], 0));
+  }
+  PT_HIP_CHECK(hipEventRecord(r->evEnd, r->stream[0]));
   return PT_OK;
 }
 int pt_timer_elapsed_ms(PtRenderer *r, float *ms) {
@@ -819,9 +855,14 @@ int pt_set_option(PtRenderer *r, int option, int value) {
   case PT_OPT_FLOAT_OUTPUT: r->floatOutput = value != 0; return PT_OK;
   case PT_OPT_VOLUME_BRICKS: r->volumeBricks = value != 0; return PT_OK;
   case PT_OPT_FRAMES_IN_FLIGHT:
-    if (value != 1 && value != 2) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_FRAMES_IN_FLIGHT takes 1 or 2");
+    if (value < 1 || value > PtRenderer::kMaxSlots) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_FRAMES_IN_FLIGHT takes 1 .. 8");
     if (sync_all(r) != PT_OK) return PT_ERR_HIP;
+    {
+      int rcSlots = ensure_slots(r, value);
+      if (rcSlots != PT_OK) return rcSlots;
+    }
     r->framesInFlight = value;
+    if (r->lastSlot >= value) r->lastSlot = 0;
     return PT_OK;
   case PT_OPT_VOLUME_FILTER:
     if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_VOLUME_FILTER takes 0 or 1");

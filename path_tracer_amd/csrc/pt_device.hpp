@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   extern __shared__ float4 s_obj[];
   const int Ns = P.numSpheres, Ne = P.numEllipsoids;
   const int nGroups = (Ns + 7) >> 3; // trips of the sphere loop: 8 spheres = 8 float4
+  const bool sphFilter = P.sphereFilter != 0;
   if (LDS_OBJECTS) {
     for (int i = threadIdx.x; i < P.imageFloat4s; i += blockDim.x) s_obj[i] = P.image[i];
     __syncthreads();
@@ -332,8 +333,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // (the bulk of the frame: no LDS instruction in the loop, operands in SGPRs; the latency is
       // hidden by the other waves) or from the LDS copy (pooled end of the frame, where few
       // waves run and the short LDS latency counts).
-      auto denseSpheres = [&](auto scalarTag, const float ox, const float oy, const float oz, const float dx, const float dy,
-                              const float dz, unsigned long long *slot, const int gBegin, const int gEnd) {
+      auto denseSpheres = [&](auto scalarTag, const bool has, const float ox, const float oy, const float oz, const float dx,
+                              const float dy, const float dz, unsigned long long *slot, const int gBegin, const int gEnd) {
         int qHead = 0, qTail = 0; // ring of 128 entries, wave-uniform cursors
         // Evaluate n <= 64 queued (lane, sphere) candidates, one per lane.
         auto drain = [&](int n) {
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           if (LDS_OBJECTS) { // the pair image starts at float4 0 of the scene image
             const float *sf = (const float *)s_obj;
             const int f = 8 * (idx >> 1) + (idx & 1);
-            cx = sf[f]; cy = sf[f + 2]; cz = sf[f + 4]; rr = sf[f + 6];
+            cx = sf[f]; cy = sf[f + 2]; cz = sf[f + 4]; rr = sf[4 * P.offRadius + idx];
           } else {
             const float4 sp = P.spheres[idx];
             cx = sp.x; cy = sp.y; cz = sp.z; rr = sp.w;
@@ -362,8 +363,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const float sq = __builtin_sqrtf(disc);
           float t = -hb - sq;
           if (t < tMin) t = -hb + sq;
+          // The packed loop's filter may let a sphere through whose discriminant is negative.
+          const bool root = on && disc >= 0.0f;
+          if (COUNT && root) cRoots++;
           // accepted iff tMin <= t <= closest-so-far; the atomic min applies the upper bound
-          if (on && !(t < tMin)) {
+          if (root && !(t < tMin)) {
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(~((unsigned int)idx + 1u));
             atomicMin(&slot[owner], key);
@@ -381,46 +385,72 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     const f2 cc = fma2(-rr, rr, dd);                                             \
     DISC = fma2(hb, hb, -cc);                                                    \
   }
+// The cheaper conservative test (see FrameParams::sphereFilter): 8 packed instructions per pair,
+// each with one scalar operand (k is added last: an instruction reads one scalar register pair).
+#define PT_PAIR_FILT(A, B, T)                                                    \
+  {                                                                              \
+    const f2 cx = mk2(A.x, A.y), cy = mk2(A.z, A.w), cz = mk2(B.x, B.y);         \
+    const f2 hb = fma2(cx, NDX, fma2(cy, NDY, fma2(cz, NDZ, OD)));               \
+    const f2 oc2 = fma2(cx, M2OX, fma2(cy, M2OY, cz * M2OZ));                    \
+    T = fma2(hb, hb, -oc2) - mk2(B.z, B.w);                                      \
+  }
 #define PT_ENQUEUE(IDX, DISC)                                                    \
   {                                                                              \
-    const bool c_ = (DISC >= 0.0f) && (IDX) < Ns;                                \
+    const bool c_ = (DISC >= thr) && (IDX) < Ns;                                 \
     const unsigned long long m_ = __ballot(c_);                                  \
     if (m_ != 0ull) {                                                            \
       const int pre_ = __popcll(m_ & laneMaskLt);                                \
-      if (c_) {                                                                  \
-        w_queue[(qTail + pre_) & 127] = (unsigned int)lane | ((unsigned int)(IDX) << 6); \
-        if (COUNT) cRoots++;                                                     \
-      }                                                                          \
+      if (c_) w_queue[(qTail + pre_) & 127] = (unsigned int)lane | ((unsigned int)(IDX) << 6); \
       qTail += __popcll(m_);                                                     \
       if (qTail - qHead >= 64) { drain(64); qHead += 64; }                       \
     }                                                                            \
   }
-        for (int g = gBegin; g < gEnd; ++g) {
+        // Per ray: o.d, -d, -2o and the threshold |o|^2 (1 - 2^-17) for the filter; 0 for the discriminant itself.
+        const float od1 = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
+        const float oo1 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+        const f2 OD = mk2(od1, od1), NDX = mk2(-dx, -dx), NDY = mk2(-dy, -dy), NDZ = mk2(-dz, -dz);
+        const f2 M2OX = mk2(-2.0f * ox, -2.0f * ox), M2OY = mk2(-2.0f * oy, -2.0f * oy), M2OZ = mk2(-2.0f * oz, -2.0f * oz);
+        auto loop = [&](auto filterTag) {
+          constexpr bool FILTER = decltype(filterTag)::value;
+          const float thr = !FILTER ? 0.0f : (has ? __builtin_fmaf(-0x1p-17f, oo1, oo1) : __builtin_inff());
+          for (int g = gBegin; g < gEnd; ++g) {
 #define PT_PAIR_AT(i) ((decltype(scalarTag)::value || !LDS_OBJECTS) ? ld_image(i) : s_obj[(i)])
-          const float4 a0 = PT_PAIR_AT(8 * g), b0 = PT_PAIR_AT(8 * g + 1), a1 = PT_PAIR_AT(8 * g + 2), b1 = PT_PAIR_AT(8 * g + 3);
-          const float4 a2 = PT_PAIR_AT(8 * g + 4), b2 = PT_PAIR_AT(8 * g + 5), a3 = PT_PAIR_AT(8 * g + 6), b3 = PT_PAIR_AT(8 * g + 7);
+            const float4 a0 = PT_PAIR_AT(8 * g), b0 = PT_PAIR_AT(8 * g + 1), a1 = PT_PAIR_AT(8 * g + 2), b1 = PT_PAIR_AT(8 * g + 3);
+            const float4 a2 = PT_PAIR_AT(8 * g + 4), b2 = PT_PAIR_AT(8 * g + 5), a3 = PT_PAIR_AT(8 * g + 6), b3 = PT_PAIR_AT(8 * g + 7);
 #undef PT_PAIR_AT
-          f2 d0, d1, d2, d3;
-          PT_PAIR_DISC(a0, b0, d0)
-          PT_PAIR_DISC(a1, b1, d1)
-          PT_PAIR_DISC(a2, b2, d2)
-          PT_PAIR_DISC(a3, b3, d3)
-          // finite rays and a finite scene give finite discriminants (no NaN to lose in max)
-          const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), __builtin_fmaxf(d1.x, d1.y)),
-                                          __builtin_fmaxf(__builtin_fmaxf(d2.x, d2.y), __builtin_fmaxf(d3.x, d3.y)));
-          if (COUNT) cGroups++;
-          if (__ballot(m >= 0.0f) != 0ull) {
-            if (COUNT) cSlow++;
-            PT_ENQUEUE(8 * g, d0.x)
-            PT_ENQUEUE(8 * g + 1, d0.y)
-            PT_ENQUEUE(8 * g + 2, d1.x)
-            PT_ENQUEUE(8 * g + 3, d1.y)
-            PT_ENQUEUE(8 * g + 4, d2.x)
-            PT_ENQUEUE(8 * g + 5, d2.y)
-            PT_ENQUEUE(8 * g + 6, d3.x)
-            PT_ENQUEUE(8 * g + 7, d3.y)
+            f2 d0, d1, d2, d3;
+            if (FILTER) {
+              PT_PAIR_FILT(a0, b0, d0)
+              PT_PAIR_FILT(a1, b1, d1)
+              PT_PAIR_FILT(a2, b2, d2)
+              PT_PAIR_FILT(a3, b3, d3)
+            } else {
+              PT_PAIR_DISC(a0, b0, d0)
+              PT_PAIR_DISC(a1, b1, d1)
+              PT_PAIR_DISC(a2, b2, d2)
+              PT_PAIR_DISC(a3, b3, d3)
+            }
+            // finite rays and a finite scene give finite values (no NaN to lose in max)
+            // (three three-input maxima and one of two)
+            float m = __builtin_fmaxf(__builtin_fmaxf(d0.x, d0.y), d1.x);
+            m = __builtin_fmaxf(__builtin_fmaxf(m, d1.y), d2.x);
+            m = __builtin_fmaxf(__builtin_fmaxf(m, d2.y), d3.x);
+            m = __builtin_fmaxf(m, d3.y);
+            if (COUNT) cGroups++;
+            if (__ballot(m >= thr) != 0ull) {
+              if (COUNT) cSlow++;
+              PT_ENQUEUE(8 * g, d0.x)
+              PT_ENQUEUE(8 * g + 1, d0.y)
+              PT_ENQUEUE(8 * g + 2, d1.x)
+              PT_ENQUEUE(8 * g + 3, d1.y)
+              PT_ENQUEUE(8 * g + 4, d2.x)
+              PT_ENQUEUE(8 * g + 5, d2.y)
+              PT_ENQUEUE(8 * g + 6, d3.x)
+              PT_ENQUEUE(8 * g + 7, d3.y)
+            }
           }
-        }
+        };
+        if (sphFilter) loop(ScalarTag{}); else loop(LdsTag{});
         if (qTail > qHead) drain(qTail - qHead);
       };
 
@@ -538,7 +568,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const float ox = has ? c_rays[at] : 4.0e9f, oy = has ? c_rays[nThreads + at] : 4.0e9f;
             const float oz = has ? c_rays[2 * nThreads + at] : 4.0e9f, dx = has ? c_rays[3 * nThreads + at] : 0.0f;
             const float dy = has ? c_rays[4 * nThreads + at] : 0.0f, dz = has ? c_rays[5 * nThreads + at] : 0.0f;
-            denseSpheres(LdsTag{}, ox, oy, oz, dx, dy, dz, c_slot + b * 64, (int)((long long)part * nGroups / split),
+            denseSpheres(LdsTag{}, has, ox, oy, oz, dx, dy, dz, c_slot + b * 64, (int)((long long)part * nGroups / split),
                          (int)((long long)(part + 1) * nGroups / split));
           }
         }
@@ -564,7 +594,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       } else if (__ballot(fastLane) != 0ull) {
-        denseSpheres(ScalarTag{}, fastLane ? rO.x : 4.0e9f, fastLane ? rO.y : 4.0e9f, fastLane ? rO.z : 4.0e9f,
+        denseSpheres(ScalarTag{}, fastLane, fastLane ? rO.x : 4.0e9f, fastLane ? rO.y : 4.0e9f, fastLane ? rO.z : 4.0e9f,
                      fastLane ? rD.x : 0.0f, fastLane ? rD.y : 0.0f, fastLane ? rD.z : 0.0f, w_slot, 0, nGroups);
       }
 

@@ -39,8 +39,10 @@ struct FrameParams {
   int volMaterial;
   // Scene image: one contiguous block of float4, copied into LDS by every
   // workgroup when it fits (offsets in float4 units):
-  //   [0)          sphere pairs, 2 float4 per pair (cx0,cx1,cy0,cy1) (cz0,cz1,r0,r1),
-  //                padded with copies of the last sphere to a multiple of 8 spheres
+  //   [0)          sphere pairs, 2 float4 per pair (cx0,cx1,cy0,cy1) (cz0,cz1,w0,w1),
+  //                padded with copies of the last sphere to a multiple of 8 spheres;
+  //                w = radius, or with sphereFilter the filter constant k (see below)
+  //   [offRadius)  one float per sphere: radius (read when a candidate's roots are evaluated)
   //   [offEll)     4 per ellipsoid: (c,qw) (1/radii,maxRadius) (-q.xyz,0) (-2q.xyz,0)
   //   [offEllPair) 7 per pair of ellipsoids, every field as (first, second) of the pair:
   //                (cx,cy) (cz,qw) (1/rx,1/ry) (1/rz,-qx) (-qy,-qz) (-2qx,-2qy) (-2qz,0); an odd
@@ -53,7 +55,7 @@ struct FrameParams {
   //   [offMatIdx)  uint16 material index per sphere, then per ellipsoid
   const float4 *image;
   int imageFloat4s;
-  int offEll, offEllPair, offMat, offLight, offEmS, offEmE, offMatIdx;
+  int offRadius, offEll, offEllPair, offMat, offLight, offEmS, offEmE, offMatIdx;
   int matIdxEllBase;         // element offset of the ellipsoid part of the uint16 table
   const float4 *spheres;     // (cx, cy, cz, r), one per sphere, global memory
   const uint8_t *voxels;   // linear (x fastest, as uploaded) when brickX == 0, else bricked
@@ -75,6 +77,12 @@ struct FrameParams {
   int fanOut;       // 1: at the end of the frame lighting rays of one pixel are spread over idle lanes (not with coop)
   int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
   float unitTol;    // |dot(d,d) - 1| up to which a ray takes the dense sphere loop
+  // 1: the dense sphere loop runs a cheaper conservative test in place of hitSphere's discriminant:
+  //   (o.d - c.d)^2 - (k - 2 o.c) >= |o|^2 (1 - 2^-17),  k = |c|^2 - r^2 - 2^-17 (|c|^2 + r^2) - 1e-30
+  // which holds whenever the float discriminant is >= 0 (rounding of both sides is below the 2^-17
+  // terms for |d|^2 <= 1.25 (1 + unitTol cap) and coordinates <= 1e9); the candidates it lets through are then
+  // evaluated with hitSphere's own operations, so the result does not change.
+  int sphereFilter;
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
   int tune;         // tuning switches of pt_set_option(100, ...), 0 in production; the kernel reads bit 0: no wave priorities
 };

@@ -129,14 +129,15 @@ def test_tile_order_and_object_source_do_not_change_the_frame():
         np.testing.assert_array_equal(frames[0].view(np.uint32), f.view(np.uint32))
 
 
-def test_two_frames_in_flight_show_the_latest_frame():
-    """Consecutive pt_render calls alternate between two slots; what readback shows is always the
+@pytest.mark.parametrize("in_flight", [2, 3, 4, 8])
+def test_frames_in_flight_show_the_latest_frame(in_flight):
+    """Consecutive pt_render calls go round the slots; what readback shows is always the
     most recent frame, bit-identical to the same frame drawn one at a time."""
     import copy
 
     sc = scenes.config2(320, 180, n_spheres=16, n_ellipsoids=5, max_depth=4)
     pcs = []
-    for k in range(4):
+    for k in range(6):
         s2 = copy.copy(sc)
         s2.camera_pos = (5.0 - 0.7 * k, 1.5 + 0.2 * k, 6.0)
         pcs.append(s2.push_constants())
@@ -144,11 +145,12 @@ def test_two_frames_in_flight_show_the_latest_frame():
     want = [_frame(solo, pc)[1].copy() for pc in pcs]
     solo.shutdown()
     assert not np.array_equal(want[0], want[1])
-    r = _renderer(sc, {T.OPT_FRAMES_IN_FLIGHT: 2})
-    for pc in pcs:          # four frames queued back to back, no wait in between
+    r = _renderer(sc, {T.OPT_FRAMES_IN_FLIGHT: in_flight})
+    for pc in pcs:          # six frames queued back to back, no wait in between
         r.render(pc)
+    assert r.lastSlot() == (len(pcs) - 1 + 1) % in_flight  # the first frame goes to slot 1
     r.present()
-    np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[3].view(np.uint32))
+    np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[5].view(np.uint32))
     for k in (1, 0, 2):     # and one by one, in another order
         r.render(pcs[k])
         np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[k].view(np.uint32))

@@ -1,4 +1,4 @@
-"""One rank's share of a 1/2/4/8-way band split, timed alone on one GPU, one frame at a time and with two in flight."""
+"""One rank's share of a 1/2/4/8-way band split, timed alone on one GPU, with 1, 2, 3, 4, 6 and 8 frames in flight."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 from path_tracer_amd import scenes, HipRenderer
@@ -10,7 +10,7 @@ pc = sc.push_constants()
 base = {}
 for world in (1, 2, 4, 8):
     out = []
-    for fif in (1, 2):
+    for fif in (1, 2, 3, 4, 6, 8):
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
         r.setOption(1, 0); r.setOption(6, fif)
         for k, val in fixed: r.setOption(k, val)
@@ -23,5 +23,5 @@ for world in (1, 2, 4, 8):
             r.timerEnd(); res.append(r.timerElapsedMs() / n)
         ms = float(np.median(res)); r.shutdown()
         if world == 1: base[fif] = ms
-        out.append(f"{fif} in flight {ms:.3f} ms ({base[fif] / ms:.2f}x of {world})")
+        out.append(f"{fif}: {ms:.3f} ms ({base[fif] / ms:.2f}x)")
     print(name, 'world', world, ' | '.join(out))
