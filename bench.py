@@ -34,6 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# A split frame is drawn with eight frame slots, one stream each; HIP gives a process four hardware queues unless
+# told otherwise, and reads this when the runtime starts: set it before anything loads HIP.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-split" in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X vector FP32, datasheet
@@ -124,8 +129,12 @@ class Runner:
     def counters(self):
         return self._reduce(self.r.renderCounted(self.pc).astype(np.float64))
 
-    def step(self):
-        self.r.render(self.pc)
+    def step(self, samples: int = 0):
+        """One frame: a plain render, or `samples` accumulated sub-pixel samples (gathered once, after the last)."""
+        if samples:
+            self.r.renderSamples(self.pc, 0, samples)
+        else:
+            self.r.render(self.pc)
         if self.split:
             if self.backend == "nccl":
                 slot = self.last = self.r.lastSlot()
@@ -255,7 +264,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the final frame against a single-GPU render")
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=range(1, 9),
                     help="frames queued at once, each on a stream of its own (default: 2 on one GPU, as the reference's "
-                         "MAX_FRAMES_IN_FLIGHT; 4 when the frame is split over several GPUs, where a rank's share is short "
+                         "MAX_FRAMES_IN_FLIGHT; 8 when the frame is split over several GPUs, where a rank's share is short "
                          "against its longest chain of dependent rays); 1: one at a time")
     ap.add_argument("--force-split", action="store_true",
                     help="testing: take the band-split + gather path even with one rank (exercises the RCCL plumbing on one GPU)")
@@ -293,7 +302,7 @@ def main():
     n_gpus = world
 
     scene = build_scene(args.workload, args.scale)
-    fif = args.frames_in_flight or (4 if (world > 1 or args.force_split) else 2)
+    fif = args.frames_in_flight or (8 if (world > 1 or args.force_split) else 2)
     run = Runner(scene, rank, world, local_rank, torch_mod, dist, args.backend, split=(world > 1 or args.force_split),
                  frames_in_flight=fif)
     cnt = run.counters()
@@ -353,7 +362,7 @@ def main():
                 "unit": unit,
                 "note": "same frames with PT_OPT_FRAMES_IN_FLIGHT = 1; the roofline object and the rocprofv3 summaries "
                         "describe this mode (a kernel running alone); the headline has frames_in_flight frames queued at "
-                        "once (2 is the library's default, as the reference's MAX_FRAMES_IN_FLIGHT; 4 with a band split)"}
+                        "once (2 is the library's default, as the reference's MAX_FRAMES_IN_FLIGHT; 8 with a band split)"}
         if check is not None:
             result["config"]["gathered_frame_equals_single_gpu_frame"] = check
         if n_gpus > 1:
@@ -397,20 +406,38 @@ def main():
                                     "pixel); rays per sample taken from sample 0"}
         result["workloads"] = extras
 
-    # N > 1: the 4K / 4096-sphere frame (the configuration the multi-GPU metric is quoted on) beside the default workload,
-    # same band split and gather; every rank takes part
-    if n_gpus > 1 and not args.no_extras and args.scale == 1.0 and args.workload != "c3":
-        sc = build_scene("c3")
-        rr = Runner(sc, rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=fif)
-        c = rr.counters()
-        k3 = 12
-        d, e = rr.timed(k3, fif)
-        rr.close()
+    # N > 1: the 4K / 4096-sphere frame (the configuration the multi-GPU metric is quoted on), the volume frame and the
+    # 64-sample 4K frame beside the default workload, same band split and gather; every rank takes part
+    if n_gpus > 1 and not args.no_extras and args.scale == 1.0:
+        extras = {}
+        for name, frames in (("c3", 16), ("c4", 32)):
+            if name == args.workload:
+                continue
+            rr = Runner(build_scene(name), rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=fif)
+            c = rr.counters()
+            d, e = rr.timed(frames, fif)
+            rr.close()
+            extras[name] = {"ms_per_frame": round(d / frames * 1e3, 4), "Mrays_per_s": round(c[0] / (d / frames) / 1e6, 2),
+                            "rays_per_frame": float(c[0]), "n_gpus": n_gpus, "frames": frames, "frames_in_flight": fif,
+                            "roofline": roofline_for(c / n_gpus, e / frames)}
+            if name == "c4":
+                extras[name]["Msamples_per_s"] = round(c[6] / (d / frames) / 1e6, 2)
+        if args.workload != "c5":
+            # every rank accumulates its bands over 64 samples, one gather after the last sample
+            spp = 64
+            rr = Runner(build_scene("c5"), rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=1)
+            c = rr.counters()
+            rr.step(samples=2)
+            rr.sync(); rr.barrier(); rr.sync()
+            t0 = time.perf_counter()
+            rr.step(samples=spp)
+            rr.sync(); rr.barrier(); rr.sync()
+            d = float(rr._reduce([time.perf_counter() - t0], "max")[0])
+            rr.close()
+            extras["c5"] = {"spp": spp, "ms_per_frame": round(d * 1e3, 3), "ms_per_sample": round(d / spp * 1e3, 4),
+                            "rays_sample0": float(c[0]), "Mrays_per_s": round(c[0] * spp / d / 1e6, 2), "n_gpus": n_gpus}
         if rank == 0:
-            result["workloads"] = {"c3": {"ms_per_frame": round(d / k3 * 1e3, 4), "Mrays_per_s": round(c[0] / (d / k3) / 1e6, 2),
-                                          "rays_per_frame": float(c[0]), "n_gpus": n_gpus, "frames": k3,
-                                          "frames_in_flight": fif,
-                                          "roofline": roofline_for(c / n_gpus, e / k3)}}
+            result["workloads"] = extras
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(scene)
