@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float diffuseStrength = glmax(0.0f, dot3(hitN, lightDir));
         const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseStrength), attenuation);
         const V3 halfDir = normalize3(add3(lightDir, viewDir));
-        const float specularStrength = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
+        const float specularStrength = highlight_pow(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
         const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularStrength), attenuation);
         lit = add3(lit, add3(diffuse, specular));
       } else if (kind == ST_TOON_LIGHT) {
@@ -834,7 +834,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float diffuseQuantized = diffuseRaw > 0.6f ? 1.0f : (diffuseRaw > 0.3f ? 0.5f : 0.0f);
         const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseQuantized), attenuation);
         const V3 halfDir = normalize3(add3(lightDir, viewDir));
-        const float specularRaw = powf(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
+        const float specularRaw = highlight_pow(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
         const float specularQuantized = specularRaw > 0.8f ? 1.0f : 0.0f;
         const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularQuantized), attenuation);
         lit = add3(lit, add3(diffuse, specular));

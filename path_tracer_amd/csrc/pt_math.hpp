@@ -90,12 +90,55 @@ __device__ __forceinline__ V3 hsl2rgb(float h, float s, float l) {
   return mk3(hue2rgb(p, q, H + 1.0f / 3.0f), hue2rgb(p, q, H), hue2rgb(p, q, H - 1.0f / 3.0f));
 }
 // rainbow.glsl:24-50 — returns result.emissive (result.color is 0)
-__device__ __forceinline__ V3 rainbow_emissive(V3 hitPoint, float emissiveStrength, float time) {
+__device__ __attribute__((noinline)) V3 rainbow_emissive(V3 hitPoint, float emissiveStrength, float time) {
   V3 sweepDir = normalize3(mk3(1.0f, 0.5f, 0.25f));
   float phase = dot3(hitPoint, sweepDir) * 2.0f + time * 0.002f;
   float cosVal = cosf(phase);
   float hue = glfract(0.5f + 0.5f * cosVal);
   return scale3(hsl2rgb(hue, 1.0f, 0.5f), emissiveStrength);
+}
+
+// pow(x, y) as GLSL's pow in calculateLighting and the toon shader (raytrace.comp:357, toon.glsl:33),
+// rounded like a correctly rounded powf (which the CPU restatement's libm is in all but a few of 10^4
+// cases).  The device library's generic powf costs about 170 instructions and ran once per pass; the
+// highlight only ever raises max(0, N.H) to the material's shininess, so the common cases are taken in
+// double precision, where x^y = 2^(y log2 x) needs no extended-precision tricks:
+//   log2(m 2^e) = e + s P(s^2), s = (m - 1)/(m + 1), m in [sqrt(1/2), sqrt(2)), P of degree 7 (error 2^-39);
+//   2^t = 2^n 2^f, n = rint(t), 2^f a degree-10 polynomial on [-1/2, 1/2] (error 2^-42);
+// one rounding to float at the end.  Finite x > 0 with finite y take it, x = 0 with y > 0 gives 0,
+// anything else (zero or negative exponents of zero, infinities, NaNs, negative x) the generic routine.
+__device__ __attribute__((noinline)) float highlight_pow(float x, float y) {
+  const bool finiteY = __builtin_fabsf(y) < __builtin_inff();
+  const bool fast = x > 0.0f && x < __builtin_inff() && finiteY;
+  const bool zero = x == 0.0f && y > 0.0f;
+  float res = 0.0f;
+  if (fast) {
+    const double xd = (double)x;
+    double m = __builtin_amdgcn_frexp_mant(xd); // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(xd);
+    if (m < 0x1.6a09e667f3bcdp-1) { m *= 2.0; e -= 1; }
+    const double a = m - 1.0, b = m + 1.0;
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    const double s = a * r, s2 = s * s;
+    const double lc[8] = {0x1.71547652b82fep+1, 0x1.ec709dc3a03fdp-1, 0x1.2776c50ef9bfep-1, 0x1.a61762a7aded9p-2, 0x1.484b13d7c02a9p-2, 0x1.0c9a84994022dp-2, 0x1.c68f568d31760p-3, 0x1.89f3b1694cffep-3};
+    double p = lc[7];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) p = __builtin_fma(p, s2, lc[k]);
+    const double l2 = __builtin_fma(s, p, (double)e);
+    double t = (double)y * l2;
+    t = __builtin_fmin(__builtin_fmax(t, -1100.0), 1100.0); // beyond: 0 or infinity either way
+    const double n = __builtin_rint(t), f = t - n;
+    const double ec[11] = {0x1.0000000000000p+0, 0x1.62e42fefa39efp-1, 0x1.ebfbdff82c58ep-3, 0x1.c6b08d704a0bfp-5, 0x1.3b2ab6fba4e77p-7, 0x1.5d87fe78a6730p-10, 0x1.430912f86c786p-13, 0x1.ffcbfc588b0c5p-17, 0x1.62c0223a5c822p-20, 0x1.b5253d395e7c1p-24, 0x1.e4cf5158b8ec7p-28};
+    double q = ec[10];
+#pragma unroll
+    for (int k = 9; k >= 0; --k) q = __builtin_fma(q, f, ec[k]);
+    res = (float)__builtin_ldexp(q, (int)n);
+  } else if (!zero) {
+    res = powf(x, y);
+  }
+  return res;
 }
 
 __device__ __forceinline__ uint32_t unorm8(float c) {
