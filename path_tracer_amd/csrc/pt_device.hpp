@@ -31,6 +31,13 @@
 namespace ptdev {
 
 // Where the dense sphere loop reads the sphere pairs from (compile-time choice per call site).
+// The lanes of the wave for which p holds, as a mask in scalar registers straight from the compare.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// How many lanes below this one are set in m (v_mbcnt_lo/hi: two instructions, no per-lane mask to keep).
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+
 struct ScalarTag { static constexpr bool value = true; };
 struct LdsTag { static constexpr bool value = false; };
 
@@ -114,7 +121,6 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   bool coop = false; // wave-uniform: this wave has joined the pooled mode
   int coopPass = 0;
   const int lane = threadIdx.x & 63;
-  const unsigned long long laneMaskLt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   // per-wave scratch behind the object image: 128-entry candidate ring + 64 result slots (1 KiB)
   const int objFloat4s = LDS_OBJECTS ? P.imageFloat4s : 0;
   float4 *const w_area = s_obj + objFloat4s + 64 * (int)(threadIdx.x >> 6);
@@ -173,7 +179,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // ------------------------------------------------------------------
     // Idle lanes take the next pixels of the pool in lane order; when the pool
     // runs out part-way, the rest continue in the next tile (fetched first).
-    const unsigned long long idleMask = __ballot(state == ST_IDLE);
+    const unsigned long long idleMask = ballot64(state == ST_IDLE);
     if (idleMask != 0ull && !(exhausted && poolNext == poolEnd)) {
       const int nIdle = __popcll(idleMask);
       const int avail = poolEnd - poolNext;
@@ -215,7 +221,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           nextTy = (int)(t / (unsigned int)P.tilesX);
         }
       }
-      const int rank = __popcll(idleMask & laneMaskLt);
+      const int rank = lanes_below(idleMask);
       int p = -1; // pixel within its tile
       bool fromNext = false;
       if (state == ST_IDLE) {
@@ -257,11 +263,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         if (PHASES) tPooled = __builtin_amdgcn_s_memtime();
       }
     }
-    if (!coop && __ballot(state != ST_IDLE) == 0ull) break;
+    if (!coop && ballot64(state != ST_IDLE) == 0ull) break;
     // Waves that carry bounced paths, or that are finishing their last pixels,
     // hold the longest chains of dependent rays: let them issue first.
     if (!(P.tune & 1)) {
-      if (exhausted || __ballot(state != ST_IDLE && bounce >= 1) != 0ull) __builtin_amdgcn_s_setprio(3);
+      if (exhausted || ballot64(state != ST_IDLE && bounce >= 1) != 0ull) __builtin_amdgcn_s_setprio(3);
       else __builtin_amdgcn_s_setprio(0);
     }
     PT_PHASE(cycRefill)
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // With only a few rays left in the wave (the end of the frame), the dense
       // loop would still cost a full pass; those rays go through the exact
       // routine instead, whose cost is per ray.
-      const bool sparse = !coop && (int)__popcll(__ballot(live)) <= P.sparseLanes;
+      const bool sparse = !coop && (int)__popcll(ballot64(live)) <= P.sparseLanes;
       const bool fastLane = live && finiteRay && unitDir && P.sceneHuge == 0 && !sparse;
       const bool special = live && !fastLane;
       // lanes whose ellipsoid roots can be deferred too: finite ray with a usable direction
@@ -396,11 +402,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   }
 #define PT_ENQUEUE(IDX, DISC)                                                    \
   {                                                                              \
-    const bool c_ = (DISC >= thr) && (IDX) < Ns;                                 \
-    const unsigned long long m_ = __ballot(c_);                                  \
+    /* (IDX) < Ns is wave-uniform: kept out of the per-lane compare */           \
+    const unsigned long long m_ = ((IDX) < Ns) ? ballot64(DISC >= thr) : 0ull;   \
     if (m_ != 0ull) {                                                            \
-      const int pre_ = __popcll(m_ & laneMaskLt);                                \
-      if (c_) w_queue[(qTail + pre_) & 127] = (unsigned int)lane | ((unsigned int)(IDX) << 6); \
+      const int pre_ = lanes_below(m_);                                          \
+      if (DISC >= thr) w_queue[(qTail + pre_) & 127] = (unsigned int)lane | ((unsigned int)(IDX) << 6); \
       qTail += __popcll(m_);                                                     \
       if (qTail - qHead >= 64) { drain(64); qHead += 64; }                       \
     }                                                                            \
@@ -437,7 +443,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             m = __builtin_fmaxf(__builtin_fmaxf(m, d2.y), d3.x);
             m = __builtin_fmaxf(m, d3.y);
             if (COUNT) cGroups++;
-            if (__ballot(m >= thr) != 0ull) {
+            if (ballot64(m >= thr) != 0ull) {
               if (COUNT) cSlow++;
               PT_ENQUEUE(8 * g, d0.x)
               PT_ENQUEUE(8 * g + 1, d0.y)
@@ -519,14 +525,14 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const int par = coopPass & 1;
         ++coopPass;
         if (PHASES && waveInBlock == 0) nPooled++;
-        if (__ballot(live) != 0ull && lane == 0) PT_CTRL_STORE(3 + par, 1);
-        const unsigned long long fm = __ballot(fastLane);
+        if (ballot64(live) != 0ull && lane == 0) PT_CTRL_STORE(3 + par, 1);
+        const unsigned long long fm = ballot64(fastLane);
         int base = 0;
         if (fm != 0ull) {
           if (lane == 0) base = atomicAdd(&c_ctrl[1 + par], (int)__popcll(fm));
           base = __builtin_amdgcn_readfirstlane(base);
         }
-        const int myPos = base + (int)__popcll(fm & laneMaskLt);
+        const int myPos = base + lanes_below(fm);
         if (fastLane) {
           c_rays[myPos] = rO.x; c_rays[nThreads + myPos] = rO.y; c_rays[2 * nThreads + myPos] = rO.z;
           c_rays[3 * nThreads + myPos] = rD.x; c_rays[4 * nThreads + myPos] = rD.y; c_rays[5 * nThreads + myPos] = rD.z;
@@ -538,13 +544,13 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         unsigned long long *const c_xslot = (unsigned long long *)(c_xrays + 7 * xCap);
         {
           const bool want = special && qLane;
-          const unsigned long long xm = __ballot(want);
+          const unsigned long long xm = ballot64(want);
           int xb = 0;
           if (xm != 0ull) {
             if (lane == 0) xb = atomicAdd(&c_ctrl[5 + par], (int)__popcll(xm));
             xb = __builtin_amdgcn_readfirstlane(xb);
           }
-          myXPos = xb + (int)__popcll(xm & laneMaskLt);
+          myXPos = xb + lanes_below(xm);
           pooledX = want && myXPos < xCap;
           if (pooledX) {
             c_xrays[myXPos] = rO.x; c_xrays[xCap + myXPos] = rO.y; c_xrays[2 * xCap + myXPos] = rO.z;
@@ -593,7 +599,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           if (key != ~0ull) w_slot[lane] = key;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      } else if (__ballot(fastLane) != 0ull) {
+      } else if (ballot64(fastLane) != 0ull) {
         denseSpheres(ScalarTag{}, fastLane, fastLane ? rO.x : 4.0e9f, fastLane ? rO.y : 4.0e9f, fastLane ? rO.z : 4.0e9f,
                      fastLane ? rD.x : 0.0f, fastLane ? rD.y : 0.0f, fastLane ? rD.z : 0.0f, w_slot, 0, nGroups);
       }
@@ -604,8 +610,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // behaviour: a NaN t is accepted and then voids the upper bound for the
       // next sphere) is reproduced chunk by chunk.
       PT_PHASE(cycSpheres)
-      unsigned long long todo = __ballot(special && !pooledX);
-      const unsigned long long finiteMask = (P.sceneHuge == 0) ? __ballot(finiteRay) : 0ull;
+      unsigned long long todo = ballot64(special && !pooledX);
+      const unsigned long long finiteMask = (P.sceneHuge == 0) ? ballot64(finiteRay) : 0ull;
       while (todo != 0ull) {
         const int owner = (int)__builtin_ctzll(todo);
         todo &= todo - 1ull;
@@ -642,8 +648,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             float v = t0;
             bool valid = root && !nanacc;
             if (t0 < tMin) { v = t1; valid = valid && !(t1 < tMin); }
-            if (COUNT) roots += (unsigned int)__popcll(__ballot(root));
-            const unsigned long long nm = __ballot(nanacc);
+            if (COUNT) roots += (unsigned int)__popcll(ballot64(root));
+            const unsigned long long nm = ballot64(nanacc);
             if (nm != 0ull) {
               const int kl = 63 - (int)__builtin_clzll(nm);
               C = __builtin_nanf("");
@@ -652,10 +658,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             }
             // accepted iff !(v > closestT); with closestT = NaN every valid root is
             const bool cand = valid && !(v > C);
-            if (__ballot(cand) != 0ull) {
+            if (ballot64(cand) != 0ull) {
               float mn = cand ? v : __builtin_inff();
               for (int off = 32; off > 0; off >>= 1) mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
-              const unsigned long long em = __ballot(cand && v == mn);
+              const unsigned long long em = ballot64(cand && v == mn);
               C = mn;
               win = base + 63 - (int)__builtin_clzll(em);
             }
@@ -707,7 +713,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       };
-      if (Ne > 0 && __ballot(qLane) != 0ull) {
+      const unsigned long long qMask = ballot64(qLane);
+      if (Ne > 0 && qMask != 0ull) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // two ellipsoids per trip, one packed instruction for both (hitEllipsoid's
         // operations, raytrace.comp:173-187, on each half)
@@ -727,14 +734,14 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const f2 hb = dot3p(ocS, dS);
           const f2 c = dot3p(ocS, ocS) - mk2(1.0f, 1.0f);
           const f2 disc = fma2(hb, hb, -(a * c));
-          if (__ballot(qLane && __builtin_fmaxf(disc.x, disc.y) >= 0.0f) != 0ull) {
+          if ((ballot64(__builtin_fmaxf(disc.x, disc.y) >= 0.0f) & qMask) != 0ull) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int j = 2 * p + u;
-              const bool cand = qLane && j < Ne && (u == 0 ? disc.x : disc.y) >= 0.0f;
-              const unsigned long long cm = __ballot(cand);
+              const bool cand = qLane && (u == 0 ? disc.x : disc.y) >= 0.0f;
+              const unsigned long long cm = (j < Ne) ? (ballot64((u == 0 ? disc.x : disc.y) >= 0.0f) & qMask) : 0ull; // j < Ne is wave-uniform
               if (cm != 0ull) {
-                const int pre = __popcll(cm & laneMaskLt);
+                const int pre = lanes_below(cm);
                 if (cand) {
                   w_queue[(qTail + pre) & 127] = (unsigned int)lane | ((unsigned int)(Ns + j) << 6);
                   if (COUNT) cERoots++;
@@ -761,7 +768,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // Rays that are not finite keep the shader's sequential loop, NaN rules and all.
     const bool seqEll = live && !qLane;
 
-    if (__ballot(seqEll) != 0ull && seqEll) {
+    if (ballot64(seqEll) != 0ull && seqEll) {
       const float ox = rO.x, oy = rO.y, oz = rO.z, dx = rD.x, dy = rD.y, dz = rD.z;
       const float tMin = kEpsilon;
       for (int j = 0; j < Ne; ++j) {
@@ -775,7 +782,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float hb = dot3(ocS, dS);
         const float c = dot3(ocS, ocS) - 1.0f;
         const float disc = __builtin_fmaf(hb, hb, -(a * c));
-        if (__ballot(!(disc < 0.0f)) != 0ull) {
+        if (ballot64(!(disc < 0.0f)) != 0ull) {
           if (!(disc < 0.0f)) {
             if (COUNT) cERoots++;
             const float sq = __builtin_sqrtf(disc);
@@ -958,7 +965,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       int step;
       // results of the rays this lane handed out last pass, in the order it would have cast them
       for (int r = 0; r < nRec; ++r) {
-        const int pos = f_roundBase[r] + (int)__popcll(f_roundMask[r] & laneMaskLt);
+        const int pos = f_roundBase[r] + lanes_below(f_roundMask[r]);
         const V3 dir = mk3(f_rec[2 * 64 + pos], f_rec[3 * 64 + pos], f_rec[4 * 64 + pos]);
         const V3 pend = mk3(f_rec[6 * 64 + pos], f_rec[7 * 64 + pos], f_rec[8 * 64 + pos]);
         applyResult(__float_as_int(f_rec[pos]), __float_as_int(f_rec[64 + pos]), f_rec[9 * 64 + pos] != 0.0f, dir,
@@ -1242,17 +1249,17 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // results in casting order, which keeps every sum in the order the shader forms it.
     // (Toon lanes stay sequential: their last step adds to the sum before the results are in.)
     if (P.fanOut && exhausted) {
-      const unsigned long long idleNow = __ballot(state == ST_IDLE);
+      const unsigned long long idleNow = ballot64(state == ST_IDLE);
       bool gen = state == ST_LIGHT || state == ST_EM_SPHERE || state == ST_EM_ELLIPSOID;
       const int helpers = (int)__popcll(idleNow);
-      if (helpers > 0 && __ballot(gen) != 0ull) {
+      if (helpers > 0 && ballot64(gen) != 0ull) {
         int total = 0;
         for (int round = 0; round < kFanRounds; ++round) {
-          const unsigned long long gm = __ballot(gen);
+          const unsigned long long gm = ballot64(gen);
           const int c = (int)__popcll(gm);
           if (c == 0 || total + c > helpers) break;
           if (gen) {
-            const int pos = total + (int)__popcll(gm & laneMaskLt);
+            const int pos = total + lanes_below(gm);
             f_rec[pos] = __int_as_float(state);
             f_rec[64 + pos] = __int_as_float(k);
             f_rec[2 * 64 + pos] = rD.x; f_rec[3 * 64 + pos] = rD.y; f_rec[4 * 64 + pos] = rD.z;
@@ -1276,7 +1283,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (state == ST_IDLE) {
-          const int q = (int)__popcll(idleNow & laneMaskLt);
+          const int q = lanes_below(idleNow);
           if (q < total) {
             rO = mk3(f_rec[10 * 64 + q], f_rec[11 * 64 + q], f_rec[12 * 64 + q]);
             rD = mk3(f_rec[2 * 64 + q], f_rec[3 * 64 + q], f_rec[4 * 64 + q]);
