@@ -334,10 +334,10 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   P.sphereFilter = r->sphereFilter ? 1 : 0;
   if (P.sphereFilter) P.unitTol = std::min(P.unitTol, 0.25f); // the filter's error bound assumes |d|^2 <= 1.25
   {
-    // Break-even between one dense pass (about 7.5 instructions per sphere, whatever the number
-    // of rays) and the exact routine (about 0.31 per sphere + 150, per ray).
+    // Break-even between one dense pass (about 7.5 instructions per sphere with the discriminant loop, 5.8 with
+    // the filter, whatever the number of rays) and the exact routine (about 0.31 per sphere + 150, per ray).
     const double ns = (double)pc->numSpheres;
-    const int t = (int)(7.5 * ns / (0.31 * ns + 150.0));
+    const int t = (int)((r->sphereFilter ? 5.8 : 7.5) * ns / (0.31 * ns + 150.0));
     P.sparseLanes = ((r->tune >> 8) & 0xff) ? ((r->tune >> 8) & 0xff) - 1 : std::min(t, 32);
   }
   long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
