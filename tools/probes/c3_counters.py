@@ -5,6 +5,8 @@ from path_tracer_amd import types as T
 name = sys.argv[1] if len(sys.argv)>1 else 'c3'
 sc = {'c3':scenes.config3,'c2':scenes.config2}[name]()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
+import os
+if os.environ.get('TUNE'): r.setOption(100,int(os.environ['TUNE']))
 r.setOption(1,0); r.setScene(sc); pc = sc.push_constants()
 cnt = r.renderCounted(pc)
 print(dict(zip(T.COUNTER_NAMES,[int(x) for x in cnt])))
