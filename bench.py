@@ -409,35 +409,39 @@ def main():
     # N > 1: the 4K / 4096-sphere frame (the configuration the multi-GPU metric is quoted on), the volume frame and the
     # 64-sample 4K frame beside the default workload, same band split and gather; every rank takes part
     if n_gpus > 1 and not args.no_extras and args.scale == 1.0:
-        extras = {}
-        for name, frames in (("c3", 16), ("c4", 32)):
-            if name == args.workload:
-                continue
-            rr = Runner(build_scene(name), rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=fif)
-            c = rr.counters()
-            d, e = rr.timed(frames, fif)
-            rr.close()
-            extras[name] = {"ms_per_frame": round(d / frames * 1e3, 4), "Mrays_per_s": round(c[0] / (d / frames) / 1e6, 2),
-                            "rays_per_frame": float(c[0]), "n_gpus": n_gpus, "frames": frames, "frames_in_flight": fif,
-                            "roofline": roofline_for(c / n_gpus, e / frames)}
-            if name == "c4":
-                extras[name]["Msamples_per_s"] = round(c[6] / (d / frames) / 1e6, 2)
-        if args.workload != "c5":
-            # every rank accumulates its bands over 64 samples, one gather after the last sample
-            spp = 64
-            rr = Runner(build_scene("c5"), rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=1)
-            c = rr.counters()
-            rr.step(samples=2)
-            rr.sync(); rr.barrier(); rr.sync()
-            t0 = time.perf_counter()
-            rr.step(samples=spp)
-            rr.sync(); rr.barrier(); rr.sync()
-            d = float(rr._reduce([time.perf_counter() - t0], "max")[0])
-            rr.close()
-            extras["c5"] = {"spp": spp, "ms_per_frame": round(d * 1e3, 3), "ms_per_sample": round(d / spp * 1e3, 4),
-                            "rays_sample0": float(c[0]), "Mrays_per_s": round(c[0] * spp / d / 1e6, 2), "n_gpus": n_gpus}
-        if rank == 0:
-            result["workloads"] = extras
+        try:
+            extras = {}
+            for name, frames in (("c3", 16), ("c4", 32)):
+                if name == args.workload:
+                    continue
+                rr = Runner(build_scene(name), rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=fif)
+                c = rr.counters()
+                d, e = rr.timed(frames, fif)
+                rr.close()
+                extras[name] = {"ms_per_frame": round(d / frames * 1e3, 4), "Mrays_per_s": round(c[0] / (d / frames) / 1e6, 2),
+                                "rays_per_frame": float(c[0]), "n_gpus": n_gpus, "frames": frames, "frames_in_flight": fif,
+                                "roofline": roofline_for(c / n_gpus, e / frames)}
+                if name == "c4":
+                    extras[name]["Msamples_per_s"] = round(c[6] / (d / frames) / 1e6, 2)
+            if args.workload != "c5":
+                # every rank accumulates its bands over 64 samples, one gather after the last sample
+                spp = 64
+                rr = Runner(build_scene("c5"), rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=1)
+                c = rr.counters()
+                rr.step(samples=2)
+                rr.sync(); rr.barrier(); rr.sync()
+                t0 = time.perf_counter()
+                rr.step(samples=spp)
+                rr.sync(); rr.barrier(); rr.sync()
+                d = float(rr._reduce([time.perf_counter() - t0], "max")[0])
+                rr.close()
+                extras["c5"] = {"spp": spp, "ms_per_frame": round(d * 1e3, 3), "ms_per_sample": round(d / spp * 1e3, 4),
+                                "rays_sample0": float(c[0]), "Mrays_per_s": round(c[0] * spp / d / 1e6, 2), "n_gpus": n_gpus}
+            if rank == 0:
+                result["workloads"] = extras
+        except Exception as exc:  # the same on every rank (a bug here must not cost the headline line)
+            if rank == 0:
+                result["workloads_error"] = repr(exc)
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(scene)
