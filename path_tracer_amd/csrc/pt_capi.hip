@@ -250,6 +250,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
       P.boxMin[i] = v.position[i] + v.v0[i]; // reference shaders/raytrace.comp:549-550
       P.boxMax[i] = v.position[i] + v.v1[i];
       P.extent[i] = v.v1[i] - v.v0[i];       // reference shaders/raytrace.comp:503
+      P.rcpExtent[i] = (float)(1.0 / (double)P.extent[i]);
     }
     P.res[0] = v.resolution_x; P.res[1] = v.resolution_y; P.res[2] = v.resolution_z;
     P.volMaterial = v.materialIndex;

@@ -1015,6 +1015,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               float acc = 0.0f;
               int stepCount = 0;
               const V3 vpos = ld3(L.volPos), lo = ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
+              const float rcpEx = L.rcpExtent[0], rcpEy = L.rcpExtent[1], rcpEz = L.rcpExtent[2];
+              const float cellTolX = 1.5f * 0x1p-22f * (float)L.res[0], cellTolY = 1.5f * 0x1p-22f * (float)L.res[1],
+                          cellTolZ = 1.5f * 0x1p-22f * (float)L.res[2];
               const uint8_t *__restrict__ vox = P.voxels;
               const bool bricked = P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
               const int nbx = P.brickX, nby = P.brickY;
@@ -1084,10 +1087,20 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                   const V3 rel = sub3(pos, vpos);
                   index[u] = -1;
                   if (u < n && !(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z)) {
-                    const float ux = (rel.x - lo.x) / ext.x;
-                    const float uy = (rel.y - lo.y) / ext.y;
-                    const float uz = (rel.z - lo.z) / ext.z;
-                    int ix = (int)(ux * rxf), iy = (int)(uy * ryf), iz = (int)(uz * rzf);
+                    // Only the integer part of ((rel - lo) / extent) * resolution is used.  With the reciprocal of the
+                    // extent (rounded once, from the host) the product differs from the shader's by less than
+                    // 1.26 * 2^-22 * resolution (one rounding of the reciprocal, one of each product, against one of
+                    // the quotient), so away from an integer by more than cellTol = 1.5 * 2^-22 * resolution it has the
+                    // same integer part; the few samples closer than that take the division.
+                    const float ax = rel.x - lo.x, ay = rel.y - lo.y, az = rel.z - lo.z;
+                    const float px = (ax * rcpEx) * rxf, py = (ay * rcpEy) * ryf, pz = (az * rcpEz) * rzf;
+                    int ix = (int)px, iy = (int)py, iz = (int)pz;
+                    const bool sure = __builtin_fabsf(__builtin_amdgcn_fractf(px) - 0.5f) < 0.5f - cellTolX &&
+                                      __builtin_fabsf(__builtin_amdgcn_fractf(py) - 0.5f) < 0.5f - cellTolY &&
+                                      __builtin_fabsf(__builtin_amdgcn_fractf(pz) - 0.5f) < 0.5f - cellTolZ;
+                    if (!sure) { // also where a product is not a number
+                      ix = (int)((ax / ext.x) * rxf); iy = (int)((ay / ext.y) * ryf); iz = (int)((az / ext.z) * rzf);
+                    }
                     ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix);
                     iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
                     iz = iz < 0 ? 0 : (iz > rz - 1 ? rz - 1 : iz);

@@ -83,6 +83,7 @@ struct FrameParams {
   // terms for |d|^2 <= 1.25 (1 + unitTol cap) and coordinates <= 1e9); the candidates it lets through are then
   // evaluated with hitSphere's own operations, so the result does not change.
   int sphereFilter;
+  float rcpExtent[3]; // 1 / extent[i], rounded once (from a double on the host): the march's fast voxel index
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
   int tune;         // tuning switches of pt_set_option(100, ...), 0 in production; the kernel reads bit 0: no wave priorities
 };
