@@ -523,18 +523,73 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     img.push_back(make_float4(-e.rotation[0], -e.rotation[1], -e.rotation[2], 0.0f));
     img.push_back(make_float4(-2.0f * e.rotation[0], -2.0f * e.rotation[1], -2.0f * e.rotation[2], 0.0f));
   }
-  // The same fields once more, two ellipsoids side by side, for the packed discriminant loop.
+  // Per pair of ellipsoids, what the packed candidate loop reads (see the kernel): centre, the matrix
+  // M = diag(1/radii) R(conjugate q) and the two constants of the margin, every field as (first, second).
+  //   R = I + 2 qw K + 2 K^2, K = cross-product matrix of -q.xyz: the map rotateByQuaternion applies
+  //   (raytrace.comp:99-115), for whatever q is stored (unit or not); 1/radii as the shader's float division.
+  //   mu: an upper bound of |M|_2 (sqrt of the largest absolute row sum of M^T M);
+  //   g = max(1/radii) (1 + 2|q||qw| + 2|q|^2) / mu: how large the intermediates of the shader's own evaluation
+  //   (and with them its rounding errors) can get against |M|.
+  //   Rounding analysis (u = 2^-24, Y = mu |o - c|, Z = mu |d|): the shader's float discriminant is within
+  //   u Z^2 ((112 g + 16.1) Y^2 + 28 g + 6.1) of the exact one, the loop's within u Z^2 (72.4 Y^2 + 20.1);
+  //   k1 and k2 are the sums with a tenth added, rounded up.
+  struct EllFilter { float c[3]; float m[9]; float k1, k2; };
+  auto ellipsoid_filter = [](const PtGPUEllipsoid &e) {
+    EllFilter f{};
+    for (int k = 0; k < 3; ++k) f.c[k] = e.center[k];
+    const double q[3] = {-(double)e.rotation[0], -(double)e.rotation[1], -(double)e.rotation[2]};
+    const double qw = (double)e.rotation[3];
+    const double K[3][3] = {{0.0, -q[2], q[1]}, {q[2], 0.0, -q[0]}, {-q[1], q[0], 0.0}};
+    double M[3][3], sigma = 0.0;
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+      const double inv = (double)(1.0f / e.radii[i]);
+      sigma = std::max(sigma, std::fabs(inv));
+      for (int j = 0; j < 3; ++j) {
+        double kk = 0.0;
+        for (int l = 0; l < 3; ++l) kk += K[i][l] * K[l][j];
+        M[i][j] = inv * ((i == j ? 1.0 : 0.0) + 2.0 * qw * K[i][j] + 2.0 * kk);
+        if (!std::isfinite(M[i][j])) ok = false;
+      }
+    }
+    double mu2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      double row = 0.0;
+      for (int j = 0; j < 3; ++j) {
+        double mtm = 0.0;
+        for (int l = 0; l < 3; ++l) mtm += M[l][i] * M[l][j];
+        row += std::fabs(mtm);
+      }
+      mu2 = std::max(mu2, row);
+    }
+    const double mu = std::sqrt(mu2) * (1.0 + 1e-12);
+    const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    const double G = 1.0 + 2.0 * qn * std::fabs(qw) + 2.0 * qn * qn;
+    const double g = sigma * G / mu;
+    const double u = 0x1p-24;
+    const double k1 = (124.0 * g + 98.0) * u * mu * mu * mu * mu, k2 = (31.0 * g + 29.0) * u * mu * mu;
+    if (ok && std::isfinite(k1) && std::isfinite(k2) && mu > 0.0 && k1 < 1.0e30 && k2 < 1.0e30) {
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) f.m[3 * i + j] = (float)M[i][j];
+      f.k1 = std::nextafterf((float)k1, INFINITY);
+      f.k2 = std::nextafterf((float)k2, INFINITY);
+    } else { // nothing to go by: always a candidate (M = 0 gives D' = 0, the margin is infinite)
+      f.k1 = 0.0f;
+      f.k2 = INFINITY;
+    }
+    return f;
+  };
   const int offEllPair = (int)img.size();
   for (int p = 0; 2 * p < num_ellipsoids; ++p) {
-    const PtGPUEllipsoid &a = ellipsoids[2 * p];
-    const PtGPUEllipsoid &b = ellipsoids[std::min(2 * p + 1, num_ellipsoids - 1)];
-    img.push_back(make_float4(a.center[0], b.center[0], a.center[1], b.center[1]));
-    img.push_back(make_float4(a.center[2], b.center[2], a.rotation[3], b.rotation[3]));
-    img.push_back(make_float4(1.0f / a.radii[0], 1.0f / b.radii[0], 1.0f / a.radii[1], 1.0f / b.radii[1]));
-    img.push_back(make_float4(1.0f / a.radii[2], 1.0f / b.radii[2], -a.rotation[0], -b.rotation[0]));
-    img.push_back(make_float4(-a.rotation[1], -b.rotation[1], -a.rotation[2], -b.rotation[2]));
-    img.push_back(make_float4(-2.0f * a.rotation[0], -2.0f * b.rotation[0], -2.0f * a.rotation[1], -2.0f * b.rotation[1]));
-    img.push_back(make_float4(-2.0f * a.rotation[2], -2.0f * b.rotation[2], 0.0f, 0.0f));
+    const EllFilter a = ellipsoid_filter(ellipsoids[2 * p]);
+    const EllFilter b = ellipsoid_filter(ellipsoids[std::min(2 * p + 1, num_ellipsoids - 1)]);
+    img.push_back(make_float4(a.c[0], b.c[0], a.c[1], b.c[1]));
+    img.push_back(make_float4(a.c[2], b.c[2], a.m[0], b.m[0]));
+    img.push_back(make_float4(a.m[1], b.m[1], a.m[2], b.m[2]));
+    img.push_back(make_float4(a.m[3], b.m[3], a.m[4], b.m[4]));
+    img.push_back(make_float4(a.m[5], b.m[5], a.m[6], b.m[6]));
+    img.push_back(make_float4(a.m[7], b.m[7], a.m[8], b.m[8]));
+    img.push_back(make_float4(a.k1, b.k1, a.k2, b.k2));
   }
   const int offMat = (int)img.size();
   for (int i = 0; i < num_materials; ++i) {

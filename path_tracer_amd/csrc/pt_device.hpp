@@ -292,6 +292,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     float bestT = rTmax;
     int bestIdx = -1;
     bool qLane = false; // this lane's ellipsoid roots may be deferred (set below)
+    float dLen2q = 0.0f; // |d|^2 of this lane's ray, for the ellipsoid filter's margin
     {
       const float tMin = kEpsilon; // every ray of the shader uses tMin = EPSILON
       const float kBig = 1.0e9f;   // |coordinates| up to here cannot overflow the discriminant
@@ -305,6 +306,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // a question of speed: the dense loop computes hitSphere's discriminant
       // whatever |d| is.)
       const float dLen2 = dot3(rD, rD);
+      dLen2q = dLen2;
       const bool unitDir = __builtin_fabsf(dLen2 - 1.0f) <= P.unitTol;
       // With only a few rays left in the wave (the end of the frame), the dense
       // loop would still cost a full pass; those rays go through the exact
@@ -706,7 +708,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float sq = __builtin_sqrtf(disc);
         float t = (-hb - sq) / a;
         if (t < tMin) t = (-hb + sq) / a;
-        if (on && !(t < tMin)) {
+        // The packed loop's filter may let an ellipsoid through whose discriminant is negative.
+        const bool root = on && disc >= 0.0f;
+        if (COUNT && root) cERoots++;
+        if (root && !(t < tMin)) {
           const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) |
                                          (unsigned long long)(~((unsigned int)(Ns + j) + 1u));
           atomicMin(&w_slot[owner], key);
@@ -716,36 +721,39 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       const unsigned long long qMask = ballot64(qLane);
       if (Ne > 0 && qMask != 0ull) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // two ellipsoids per trip, one packed instruction for both (hitEllipsoid's
-        // operations, raytrace.comp:173-187, on each half)
+        // Two ellipsoids per trip, one packed instruction for both.  The loop only selects candidates for
+        // drainE, which evaluates hitEllipsoid proper; it may select too many, never too few.  It evaluates
+        // hitEllipsoid's quadratic (raytrace.comp:173-187) through one matrix per ellipsoid,
+        // M = diag(1/radii) R(conjugate q) (from the host, in double precision, rounded once):
+        //   y = M (o - c), z = M d, D' = (y.z)^2 - (z.z)(y.y - 1)
+        // and adds what the two evaluations can differ by in float32, |d|^2 (k1 |o - c|^2 + k2), with
+        // k1 = (124 g + 98) u mu^4, k2 = (31 g + 29) u mu^2, u = 2^-24, mu >= |M|_2 and g the size of the
+        // shader's intermediates against mu (see pt_update_scene): 38 packed instructions instead of 57.
         const P3 RO = splat3(rO), RD = splat3(rD);
+        const f2 DD = mk2(dLen2q, dLen2q);
         for (int p = 0; 2 * p < Ne; ++p) {
           const float4 g0 = PT_ELLP(p, 0), g1 = PT_ELLP(p, 1), g2 = PT_ELLP(p, 2), g3 = PT_ELLP(p, 3);
           const float4 g4 = PT_ELLP(p, 4), g5 = PT_ELLP(p, 5), g6 = PT_ELLP(p, 6);
-          const P3 ctr = mkp3(mk2(g0.x, g0.y), mk2(g0.z, g0.w), mk2(g1.x, g1.y));
-          const f2 qw = mk2(g1.z, g1.w);
-          const P3 invR = mkp3(mk2(g2.x, g2.y), mk2(g2.z, g2.w), mk2(g3.x, g3.y));
-          const P3 nq = mkp3(mk2(g3.z, g3.w), mk2(g4.x, g4.y), mk2(g4.z, g4.w));
-          const P3 nq2 = mkp3(mk2(g5.x, g5.y), mk2(g5.z, g5.w), mk2(g6.x, g6.y));
-          const P3 oc = rotate_qp(sub3p(RO, ctr), nq, nq2, qw);
-          const P3 dir = rotate_qp(RD, nq, nq2, qw);
-          const P3 ocS = mul3p(oc, invR), dS = mul3p(dir, invR);
-          const f2 a = dot3p(dS, dS);
-          const f2 hb = dot3p(ocS, dS);
-          const f2 c = dot3p(ocS, ocS) - mk2(1.0f, 1.0f);
+          const P3 x = sub3p(RO, mkp3(mk2(g0.x, g0.y), mk2(g0.z, g0.w), mk2(g1.x, g1.y)));
+          const P3 m0 = mkp3(mk2(g1.z, g1.w), mk2(g2.x, g2.y), mk2(g2.z, g2.w));
+          const P3 m1 = mkp3(mk2(g3.x, g3.y), mk2(g3.z, g3.w), mk2(g4.x, g4.y));
+          const P3 m2 = mkp3(mk2(g4.z, g4.w), mk2(g5.x, g5.y), mk2(g5.z, g5.w));
+          const P3 y = mkp3(dot3p(m0, x), dot3p(m1, x), dot3p(m2, x));
+          const P3 z = mkp3(dot3p(m0, RD), dot3p(m1, RD), dot3p(m2, RD));
+          const f2 a = dot3p(z, z);
+          const f2 hb = dot3p(y, z);
+          const f2 c = fma2(y.z, y.z, fma2(y.y, y.y, fma2(y.x, y.x, mk2(-1.0f, -1.0f))));
           const f2 disc = fma2(hb, hb, -(a * c));
-          if ((ballot64(__builtin_fmaxf(disc.x, disc.y) >= 0.0f) & qMask) != 0ull) {
+          const f2 val = fma2(mk2(g6.x, g6.y) * DD, dot3p(x, x), fma2(mk2(g6.z, g6.w), DD, disc));
+          if ((ballot64(__builtin_fmaxf(val.x, val.y) >= -1.0e-30f) & qMask) != 0ull) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int j = 2 * p + u;
-              const bool cand = qLane && (u == 0 ? disc.x : disc.y) >= 0.0f;
-              const unsigned long long cm = (j < Ne) ? (ballot64((u == 0 ? disc.x : disc.y) >= 0.0f) & qMask) : 0ull; // j < Ne is wave-uniform
+              const bool cand = qLane && (u == 0 ? val.x : val.y) >= -1.0e-30f;
+              const unsigned long long cm = (j < Ne) ? (ballot64((u == 0 ? val.x : val.y) >= -1.0e-30f) & qMask) : 0ull; // j < Ne is wave-uniform
               if (cm != 0ull) {
                 const int pre = lanes_below(cm);
-                if (cand) {
-                  w_queue[(qTail + pre) & 127] = (unsigned int)lane | ((unsigned int)(Ns + j) << 6);
-                  if (COUNT) cERoots++;
-                }
+                if (cand) w_queue[(qTail + pre) & 127] = (unsigned int)lane | ((unsigned int)(Ns + j) << 6);
                 qTail += __popcll(cm);
                 if (qTail - qHead >= 64) { drainE(64); qHead += 64; }
               }

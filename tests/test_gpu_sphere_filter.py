@@ -67,3 +67,43 @@ def test_filter_on_off_and_oracle_agree(oracle, name, sc):
     np.testing.assert_array_equal(c_on[:NA], c_off[:NA])
     _, _, rc = oracle.render(sc, nthreads=16)
     np.testing.assert_array_equal(c_on[:NA], rc[:NA])  # same rays, same roots as the shader's loop
+
+
+def _ellipsoid_cases():
+    """Scenes that stress the packed ellipsoid loop's candidate filter (a cheaper evaluation of
+    hitEllipsoid's quadratic plus a margin for the rounding of both): strong anisotropy, quaternions
+    that are not unit, ellipsoids far from the origin, many grazing rays."""
+    rng = np.random.default_rng(5)
+    sc = scenes.config2(256, 144, n_spheres=6, n_ellipsoids=24, max_depth=4)
+    yield "c2_many_ellipsoids", sc
+    sc = scenes.config2(224, 126, n_spheres=4, n_ellipsoids=16, max_depth=3)
+    sc.ellipsoids["radii"][:, 0] *= 0.12   # needles and discs: anisotropy up to ~30
+    sc.ellipsoids["radii"][8:, 1] *= 3.0
+    yield "needles_and_discs", sc
+    sc = scenes.config2(224, 126, n_spheres=4, n_ellipsoids=16, max_depth=3)
+    sc.ellipsoids["rotation"] *= rng.uniform(0.4, 2.5, size=(16, 1)).astype(np.float32)  # not rotations: the shader's map as is
+    yield "non_unit_quaternions", sc
+    sc = scenes.config2(192, 108, n_spheres=4, n_ellipsoids=12, max_depth=3)
+    shift = np.asarray((600.0, -30.0, 450.0), np.float32)
+    sc.spheres["center"] += shift
+    sc.ellipsoids["center"] += shift
+    sc.camera_pos = tuple(np.asarray(sc.camera_pos, np.float32) + shift)
+    yield "ellipsoids_far_from_origin", sc
+    sc = scenes.config2(256, 144, n_spheres=2, n_ellipsoids=14, max_depth=3)
+    for i in range(12):                      # a row of equal flat ellipsoids seen edge-on
+        sc.ellipsoids["center"][i] = (-3.0 + 0.8 * i, 1.5, 0.0)
+        sc.ellipsoids["radii"][i] = (0.45, 0.05, 0.3)
+        sc.ellipsoids["rotation"][i] = (0.0, 0.0, 0.0, 1.0)
+    yield "grazing_discs", sc
+
+
+@pytest.mark.parametrize("name,sc", list(_ellipsoid_cases()), ids=[n for n, _ in _ellipsoid_cases()])
+def test_ellipsoid_filter_keeps_every_root(oracle, name, sc):
+    f_gpu, cnt = _frame(sc, 0)
+    r8, rf, rc = oracle.render(sc, nthreads=16)
+    np.testing.assert_array_equal(cnt[:NA], rc[:NA])  # same rays, same roots as hitEllipsoid in the shader's loop
+    err = np.abs(f_gpu - rf)
+    ok = (err <= 1e-4 * np.maximum(np.abs(rf), 1e-2)) | (np.isnan(f_gpu) & np.isnan(rf))
+    frac = float(ok.all(axis=-1).mean())
+    print(f"[{name}] float<=1e-4 {frac:.6f}")
+    assert frac >= 0.999
