@@ -45,7 +45,8 @@ struct FrameParams {
   //   [offRadius)  one float per sphere: radius (read when a candidate's roots are evaluated)
   //   [offEll)     4 per ellipsoid: (c,qw) (1/radii,maxRadius) (-q.xyz,0) (-2q.xyz,0)
   //   [offEllPair) 7 per pair of ellipsoids, every field as (first, second) of the pair:
-  //                (cx,cy) (cz,qw) (1/rx,1/ry) (1/rz,-qx) (-qy,-qz) (-2qx,-2qy) (-2qz,0); an odd
+  //                (cx,cy) (cz,m00) (m01,m02) (m10,m11) (m12,m20) (m21,m22) (k1,k2): centre, the matrix
+  //                M = diag(1/radii) R(conjugate q) and the margin constants of the candidate loop; an odd
   //                count is padded with a copy of the last ellipsoid
   //   [offMat)     5 per material, as GPUMaterial
   //   [offLight)   1 per light: (pos, intensity)
