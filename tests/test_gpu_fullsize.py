@@ -93,6 +93,26 @@ def test_c4_full_size_sampled_rows(oracle):
     assert c["voxel_samples"] > 10_000_000
 
 
+def test_c5_full_size_sampled_rows(oracle):
+    """4K, C2's objects and the volume in one frame (one sample per pixel: the reference's sample)."""
+    sc = scenes.config5()
+    g8, gf, cnt = _render(sc)
+    rows = list(range(53, sc.height, sc.height // 10))[:10]
+    _rows_match(g8, gf, sc, oracle, rows, "c5 full")
+    c = _counter_identities(cnt, sc)
+    assert c["voxel_samples"] > 10_000_000 and c["ellipsoid_roots"] > 0
+
+
+def test_demo_scene_1080p_sampled_rows(oracle):
+    """The reference's demo scene (src/main_vulkan.cpp:136-223) at orbit frame 40, 1080p, ten bounces, rainbow shader
+    at time 1234 ms, walnut volume."""
+    sc = scenes.demo_scene(1920, 1080, frame=40, with_volume=True, time_ms=1234.0)
+    g8, gf, cnt = _render(sc)
+    rows = list(range(29, sc.height, sc.height // 16))[:16]
+    _rows_match(g8, gf, sc, oracle, rows, "demo 1080p")
+    _counter_identities(cnt, sc)
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (101, 37), (65, 129)])
 def test_odd_frame_sizes(oracle, w, h):
     sc = scenes.config2(w, h, n_spheres=10, n_ellipsoids=3, max_depth=3)
