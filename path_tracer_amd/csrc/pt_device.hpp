@@ -683,8 +683,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       PT_PHASE(cycExact)
 
       // hitEllipsoid (raytrace.comp:171-210), after the spheres as in traceRay.
-      // Same scheme as the spheres: the wave-uniform loop computes every lane's
-      // discriminant, roots go through the queue and are evaluated 64 at a time.
+      // Same scheme as the spheres: a wave-uniform loop selects candidates (never too few), the queue
+      // evaluates them 64 at a time with hitEllipsoid's own operations.
       // (a = |dirScaled|^2 is part of the test, so non-unit directions are fine.)
       int qHead = 0, qTail = 0; // the candidate ring is empty again
       auto drainE = [&](int n) {
