@@ -123,6 +123,7 @@ struct PtRenderer {
   //   bit 2       discriminants in the dense sphere loop, no filter; bit 3: the filter whatever its margin costs
   //               (both read by pt_update_scene)
   //   bits 5-7    unit-direction tolerance x 2^n        bits 8-15   sparse-mode lane threshold + 1
+  //   bit 24      the tolerance also for directions shorter than 1 (as before the loop took those)
   //   bits 16-20  waves per workgroup, bits 21-23 workgroups per CU (0: chosen from the scene size)
   int tune = 0;
   void *extRgba8[kMaxSlots] = {}, *extF32[kMaxSlots] = {}; // caller-owned output per slot (pt_set_output: slot 0, pt_set_slot)
@@ -331,9 +332,12 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     P.accumCount = r->accumCount + 1;
   }
   P.tune = r->tune;
-  P.unitTol = 0.25f * (float)(1 << ((r->tune >> 5) & 7)); // measured optimum on C3 (4096 spheres): broad, 0.06 .. 1
+  // Directions longer than 1 by more than this take the exact routine (too many spheres would be candidates);
+  // measured optimum on C3 (4096 spheres): 0.25, broad.  Shorter directions have fewer candidates and all take the loop.
+  P.unitTol = 0.25f * (float)(1 << ((r->tune >> 5) & 7));
   P.sphereFilter = r->sphereFilter ? 1 : 0;
-  if (P.sphereFilter) P.unitTol = std::min(P.unitTol, 0.25f); // the filter's error bound assumes |d|^2 <= 1.25
+  if (P.sphereFilter) P.unitTol = std::min(P.unitTol, 0.75f); // the filter's error bound is derived for |d|^2 <= 1.75
+  P.unitTolLow = (r->tune & (1 << 24)) ? P.unitTol : 1.0f;
   {
     // Break-even between one dense pass (about 7.5 instructions per sphere with the discriminant loop, 5.8 with
     // the filter, whatever the number of rays) and the exact routine (about 0.31 per sphere + 150, per ray).

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       // whatever |d| is.)
       const float dLen2 = dot3(rD, rD);
       dLen2q = dLen2;
-      const bool unitDir = __builtin_fabsf(dLen2 - 1.0f) <= P.unitTol;
+      const bool unitDir = dLen2 - 1.0f <= P.unitTol && 1.0f - dLen2 <= P.unitTolLow;
       // With only a few rays left in the wave (the end of the frame), the dense
       // loop would still cost a full pass; those rays go through the exact
       // routine instead, whose cost is per ray.

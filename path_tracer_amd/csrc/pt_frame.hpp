@@ -77,11 +77,12 @@ struct FrameParams {
   float4 *accum;    // running sum of the clamped samples per pixel, or null
   int fanOut;       // 1: at the end of the frame lighting rays of one pixel are spread over idle lanes (not with coop)
   int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
-  float unitTol;    // |dot(d,d) - 1| up to which a ray takes the dense sphere loop
+  float unitTol;    // dot(d,d) - 1 up to which a ray takes the dense sphere loop (longer: too many spheres are candidates)
+  float unitTolLow; // 1 - dot(d,d) up to which it does (1: any shorter direction; those have fewer candidates, not more)
   // 1: the dense sphere loop runs a cheaper conservative test in place of hitSphere's discriminant:
   //   (o.d - c.d)^2 - (k - 2 o.c) >= |o|^2 (1 - 2^-17),  k = |c|^2 - r^2 - 2^-17 (|c|^2 + r^2) - 1e-30
   // which holds whenever the float discriminant is >= 0 (rounding of both sides is below the 2^-17
-  // terms for |d|^2 <= 1.25 (1 + unitTol cap) and coordinates <= 1e9); the candidates it lets through are then
+  // terms for |d|^2 <= 1.75 (1 + unitTol cap; shorter directions only make the rounding terms smaller) and coordinates <= 1e9); the candidates it lets through are then
   // evaluated with hitSphere's own operations, so the result does not change.
   int sphereFilter;
   float rcpExtent[3]; // 1 / extent[i], rounded once (from a double on the host): the march's fast voxel index

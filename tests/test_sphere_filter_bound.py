@@ -7,7 +7,7 @@ the kernel and the oracle use) is negative.  The loop tests
     (o.d - c.d)^2 + 2 o.c - k  >=  |o|^2 (1 - 2^-17),
     k = |c|^2 - r^2 - 2^-17 (|c|^2 + r^2) - 1e-30   (rounded down to float32)
 
-for rays with | |d|^2 - 1 | <= 0.25 and coordinates up to 1e9.  Here both sides are evaluated
+for rays with |d|^2 <= 1.25 (any shorter direction included) and coordinates up to 1e9.  Here both sides are evaluated
 with the same operation order as the kernel on random and on adversarial inputs (grazing rays,
 scenes far from the origin, tiny spheres): wherever the discriminant is >= 0 the filter must pass.
 float32 fused multiply-add is emulated in float64 (the product of two float32 is exact there;
@@ -62,7 +62,7 @@ def _rays_towards(rng, n, c, r, scale, graze):
     perp /= np.linalg.norm(perp, axis=0) + 1e-30
     target = to_c + perp * (r.astype(np.float64) * graze)
     dirn = target / (np.linalg.norm(target, axis=0) + 1e-30)
-    length = np.sqrt(rng.uniform(0.75, 1.25, size=n))
+    length = np.sqrt(rng.uniform(0.0, 1.25, size=n) ** rng.choice([1.0, 4.0], size=n))  # also far shorter than 1
     d = [(dirn[i] * length).astype(f32) for i in range(3)]
     return o, d
 
@@ -79,13 +79,13 @@ def test_filter_never_rejects_a_sphere_the_shader_would_evaluate():
         for graze in (0.0, 0.9, 0.999, 0.99999, 1.0, 1.00001, 1.001):
             o, d = _rays_towards(rng, n, c, r, scale, graze)
             dd = fma(d[2], d[2], fma(d[1], d[1], (d[0] * d[0]).astype(f32)))
-            ok_ray = np.abs(dd - f32(1.0)) <= f32(0.25)
+            ok_ray = dd - f32(1.0) <= f32(0.25)  # shorter directions take the loop too
             disc = discriminant(o, d, c, r)
             need = ok_ray & (disc >= 0)
             got = filter_passes(o, d, c, k)
             assert not (need & ~got).any(), (scale, graze, int((need & ~got).sum()))
             checked += int(ok_ray.sum()); roots += int(need.sum()); passed += int((got & ok_ray).sum())
-    assert roots > 0.2 * checked            # the adversarial part of the sample is real
+    assert roots > 0.1 * checked            # the adversarial part of the sample is real
     print(f"[sphere filter] {checked} ray-sphere pairs, {roots} with a root, {passed} let through")
 
 
