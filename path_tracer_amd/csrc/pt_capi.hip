@@ -359,16 +359,22 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     PT_HIP_CHECK(hipGetLastError());
   }
   dim3 grid(blocks), block(threads);
+#define PT_LAUNCH_K(MODE_, LDS_, POOLED_)                                                                    \
+  {                                                                                                          \
+    if (LDS_)                                                                                                \
+      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, LDS_, POOLED_>,          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));          \
+    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, LDS_, POOLED_>), grid, block, ldsBytes, stream, P);   \
+  }
 #define PT_LAUNCH(MODE_)                                                                                     \
   if (useLds) {                                                                                              \
-    PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, true>,                     \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));            \
-    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, true>), grid, block, ldsBytes, stream, P);            \
+    if (P.coop) PT_LAUNCH_K(MODE_, true, true) else PT_LAUNCH_K(MODE_, true, false)                          \
   } else {                                                                                                   \
-    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, false>), grid, block, ldsBytes, stream, P);           \
+    if (P.coop) PT_LAUNCH_K(MODE_, false, true) else PT_LAUNCH_K(MODE_, false, false)                        \
   }
   if (mode == 1) { PT_LAUNCH(1) } else if (mode == 2) { PT_LAUNCH(2) } else { PT_LAUNCH(0) }
 #undef PT_LAUNCH
+#undef PT_LAUNCH_K
   PT_HIP_CHECK(hipGetLastError());
   r->lastSlot = slot;
   r->lastBlocks = blocks;

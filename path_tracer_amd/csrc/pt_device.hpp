@@ -57,8 +57,12 @@ enum : int {
 // wave trips (what the oracle counts, for parity checks and the bench's ray
 // count).  MODE 2: production code plus per-phase cycle sums per wave (kept
 // apart from MODE 1, whose extra registers would distort the timing).
-template <int MODE, bool LDS_OBJECTS>
+// POOLED: the variant for scenes whose frames end in pooled passes (P.coop: many spheres); the other variant is the one
+// that can fan lighting rays out (P.fanOut).  The host launches the one that matches; each carries only its own code.
+template <int MODE, bool LDS_OBJECTS, bool POOLED>
 __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
+  const bool poolingOn = POOLED && P.coop != 0;
+  const bool fanOutOn = !POOLED && P.fanOut != 0;
   constexpr bool COUNT = MODE == 1;
   constexpr bool PHASES = MODE == 2;
   extern __shared__ float4 s_obj[];
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #define PT_CTRL_STORE(i, v) __hip_atomic_store(&c_ctrl[(i)], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
   float *const c_rays = (float *)(coopBase + 64);
   unsigned long long *const c_slot = (unsigned long long *)(coopBase + 64 + 6 * sizeof(float) * (size_t)nThreads);
-  if (P.coop && threadIdx.x < 8) PT_CTRL_STORE(threadIdx.x, 0);
+  if (poolingOn && threadIdx.x < 8) PT_CTRL_STORE(threadIdx.x, 0);
   __syncthreads(); // the table and the control words are in place
   bool coop = false; // wave-uniform: this wave has joined the pooled mode
   int coopPass = 0;
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         poolNext += nIdle;
       }
     }
-    if (P.coop && !coop) {
+    if (poolingOn && !coop) {
       // The first wave of the workgroup that finds every ticket group drained asks
       // all of them to switch; each joins at the top of its next pass.
       if (exhausted && lane == 0) PT_CTRL_STORE(0, 1);
@@ -421,11 +425,13 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         auto loop = [&](auto filterTag) {
           constexpr bool FILTER = decltype(filterTag)::value;
           const float thr = !FILTER ? 0.0f : (has ? __builtin_fmaf(-0x1p-17f, oo1, oo1) : __builtin_inff());
-          for (int g = gBegin; g < gEnd; ++g) {
 #define PT_PAIR_AT(i) ((decltype(scalarTag)::value || !LDS_OBJECTS) ? ld_image(i) : s_obj[(i)])
-            const float4 a0 = PT_PAIR_AT(8 * g), b0 = PT_PAIR_AT(8 * g + 1), a1 = PT_PAIR_AT(8 * g + 2), b1 = PT_PAIR_AT(8 * g + 3);
-            const float4 a2 = PT_PAIR_AT(8 * g + 4), b2 = PT_PAIR_AT(8 * g + 5), a3 = PT_PAIR_AT(8 * g + 6), b3 = PT_PAIR_AT(8 * g + 7);
-#undef PT_PAIR_AT
+#define PT_LOAD8(A0, B0, A1, B1, A2, B2, A3, B3, G)                                                                      \
+  A0 = PT_PAIR_AT(8 * (G)); B0 = PT_PAIR_AT(8 * (G) + 1); A1 = PT_PAIR_AT(8 * (G) + 2); B1 = PT_PAIR_AT(8 * (G) + 3);     \
+  A2 = PT_PAIR_AT(8 * (G) + 4); B2 = PT_PAIR_AT(8 * (G) + 5); A3 = PT_PAIR_AT(8 * (G) + 6); B3 = PT_PAIR_AT(8 * (G) + 7);
+          // one trip: eight spheres against the wave's rays
+          auto trip = [&](const int g, const float4 a0, const float4 b0, const float4 a1, const float4 b1, const float4 a2,
+                          const float4 b2, const float4 a3, const float4 b3) {
             f2 d0, d1, d2, d3;
             if (FILTER) {
               PT_PAIR_FILT(a0, b0, d0)
@@ -456,7 +462,35 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               PT_ENQUEUE(8 * g + 6, d3.x)
               PT_ENQUEUE(8 * g + 7, d3.y)
             }
+          };
+          if (POOLED && decltype(scalarTag)::value) { // many spheres: worth the second set of registers
+            // Two sets of scalar registers take turns: the next trip's spheres are requested as soon as this trip's
+            // have arrived (scalar loads return in any order, so a wait is a wait for all of them: it has to come
+            // before the next request goes out), and arrive while this trip computes.
+            float4 pa0, pb0, pa1, pb1, pa2, pb2, pa3, pb3, qa0, qb0, qa1, qb1, qa2, qb2, qa3, qb3;
+            if (gBegin < gEnd) { PT_LOAD8(pa0, pb0, pa1, pb1, pa2, pb2, pa3, pb3, gBegin) }
+            for (int g = gBegin; g < gEnd; g += 2) {
+              const int g1 = g + 1 < gEnd ? g + 1 : g;
+              __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the p set is there
+              PT_LOAD8(qa0, qb0, qa1, qb1, qa2, qb2, qa3, qb3, g1)
+              __builtin_amdgcn_sched_barrier(0);
+              trip(g, pa0, pb0, pa1, pb1, pa2, pb2, pa3, pb3);
+              if (g + 1 >= gEnd) break;
+              const int g2 = g + 2 < gEnd ? g + 2 : g + 1;
+              __builtin_amdgcn_s_waitcnt(0xC07F); // the q set is there
+              PT_LOAD8(pa0, pb0, pa1, pb1, pa2, pb2, pa3, pb3, g2)
+              __builtin_amdgcn_sched_barrier(0);
+              trip(g + 1, qa0, qb0, qa1, qb1, qa2, qb2, qa3, qb3);
+            }
+          } else {
+            for (int g = gBegin; g < gEnd; ++g) {
+              float4 a0, b0, a1, b1, a2, b2, a3, b3;
+              PT_LOAD8(a0, b0, a1, b1, a2, b2, a3, b3, g)
+              trip(g, a0, b0, a1, b1, a2, b2, a3, b3);
+            }
           }
+#undef PT_LOAD8
+#undef PT_PAIR_AT
         };
         if (sphFilter) loop(ScalarTag{}); else loop(LdsTag{});
         if (qTail > qHead) drain(qTail - qHead);
@@ -959,7 +993,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       } while (0);
     };
 
-    if (P.fanOut) {
+    if (fanOutOn) {
       // helpers report, then go back to being idle
       if (state == ST_JOB) {
         f_rec[9 * 64 + jobPos] = hitAny ? 1.0f : 0.0f;
@@ -1269,7 +1303,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // last ray itself.  Next pass the helpers report hit or miss and the lane applies the
     // results in casting order, which keeps every sum in the order the shader forms it.
     // (Toon lanes stay sequential: their last step adds to the sum before the results are in.)
-    if (P.fanOut && exhausted) {
+    if (fanOutOn && exhausted) {
       const unsigned long long idleNow = ballot64(state == ST_IDLE);
       bool gen = state == ST_LIGHT || state == ST_EM_SPHERE || state == ST_EM_ELLIPSOID;
       const int helpers = (int)__popcll(idleNow);
