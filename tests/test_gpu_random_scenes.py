@@ -140,3 +140,35 @@ def test_random_hall_of_mirrors_matches_the_oracle(oracle, seed):
     okf = ((np.abs(gf - rf) <= 1e-4 * np.maximum(np.abs(rf), 1e-2)) | both_nan).all(axis=-1)
     print(f"[{sc.name}] {len(sc.spheres)} spheres, depth {sc.max_depth}, exact rays {c['exact_rays']}, pooled passes {c['pooled_passes']}")
     assert float((d8 <= 1).mean()) >= 0.999 and float(okf.mean()) >= 0.999
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_volume_modes_match_the_oracle(oracle, seed):
+    """Random scenes that have a volume, drawn with the linear or the bricked voxel copy and with the nearest or
+    the trilinear filter (the oracle states the same filter); two samples per pixel on the odd seeds."""
+    from path_tracer_amd import HipRenderer
+
+    base = 3000 + seed
+    sc = random_scene(base)
+    while len(sc.volumes) == 0:
+        base += 100
+        sc = random_scene(base)
+    bricks, trilinear, samples = seed & 1, (seed >> 1) & 1, 1 + (seed % 3 == 1)
+    r = HipRenderer()
+    assert r.initialize(sc.width, sc.height)
+    r.setOption(T.OPT_VOLUME_BRICKS, bricks)
+    r.setOption(T.OPT_VOLUME_FILTER, trilinear)
+    r.setScene(sc)
+    pc = sc.push_constants()
+    if samples > 1:
+        r.renderSamples(pc, 0, samples)
+    else:
+        r.render(pc)
+    r.present()
+    g8, gf = r.readbackRGBA8(), r.readbackF32()
+    r.shutdown()
+    r8, rf, _ = oracle.render(sc, nthreads=8, volume_filter=trilinear, num_samples=samples)
+    d8 = np.abs(g8.astype(np.int16) - r8.astype(np.int16)).max(axis=-1)
+    both_nan = np.isnan(gf) & np.isnan(rf)
+    okf = ((np.abs(gf - rf) <= 1e-4 * np.maximum(np.abs(rf), 1e-2)) | both_nan).all(axis=-1)
+    assert float((d8 <= 1).mean()) >= 0.999 and float(okf.mean()) >= 0.999, (sc.name, bricks, trilinear, samples)
