@@ -1,0 +1,31 @@
+"""Long differential run, by hand: python tests/fuzz_random_scenes.py [first_seed] [count]
+Random scenes of tests/test_gpu_random_scenes.py (both generators) against the oracle; prints the seeds that differ."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from path_tracer_amd import HipRenderer, types as T
+from oracle import oracle_py
+import test_gpu_random_scenes as G
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+oracle_py.lib()
+orc = oracle_py
+bad = []
+for seed in range(first, first + count):
+    sc = G.random_hall_of_mirrors(seed) if seed % 10 == 0 else G.random_scene(seed)
+    r = HipRenderer(); assert r.initialize(sc.width, sc.height)
+    r.setScene(sc); pc = sc.push_constants()
+    r.render(pc); r.present()
+    g8, gf = r.readbackRGBA8(), r.readbackF32()
+    cnt = r.renderCounted(pc); r.shutdown()
+    r8, rf, rc = orc.render(sc, nthreads=16)
+    same_cnt = np.array_equal(cnt[:T.N_ALGORITHM_COUNTERS], rc[:T.N_ALGORITHM_COUNTERS])
+    d8 = np.abs(g8.astype(np.int16) - r8.astype(np.int16)).max(axis=-1)
+    okf = ((np.abs(gf - rf) <= 1e-4 * np.maximum(np.abs(rf), 1e-2)) | (np.isnan(gf) & np.isnan(rf))).all(axis=-1)
+    if not same_cnt or (d8 <= 1).mean() < 0.999 or okf.mean() < 0.999:
+        bad.append(seed); print("DIFF", seed, same_cnt, float((d8 <= 1).mean()), float(okf.mean()), flush=True)
+    if (seed - first) % 100 == 99: print("done", seed - first + 1, "bad", len(bad), flush=True)
+print("seeds that differ:", bad)
+sys.exit(1 if bad else 0)
