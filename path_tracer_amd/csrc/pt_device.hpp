@@ -83,7 +83,6 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     return make_float4(v.x, v.y, v.z, v.w);
   };
 #define PT_IMG(i) (LDS_OBJECTS ? s_obj[(i)] : ld_image(i))
-#define PT_PAIR(i) PT_IMG(i)
 #define PT_ELL(j, k) PT_IMG(P.offEll + 4 * (j) + (k))
 #define PT_ELLP(p, k) ld_image(P.offEllPair + 7 * (p) + (k)) /* wave-uniform: scalar loads, like the sphere pairs */
 #define PT_MAT(m, k) PT_IMG(P.offMat + 5 * (m) + (k))
@@ -1392,7 +1391,6 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #undef PT_CTRL_LOAD
 #undef PT_CTRL_STORE
 #undef PT_IMG
-#undef PT_PAIR
 #undef PT_ELL
 #undef PT_MAT
 #undef PT_LIGHT
