@@ -32,10 +32,9 @@ int main(int argc, char *argv[]) {
   const int WINDOW_HEIGHT = argc > 3 ? std::atoi(argv[3]) : 600;
   const std::string outDir = argc > 4 ? argv[4] : ".";
   const float dtMs = argc > 5 ? (float)std::atof(argv[5]) : 1000.0f / 120.0f;
-  const int MAX_DEPTH = 5; // the reference passes 5 and its shader ignores it
+  const int MAX_DEPTH = 5; // the reference passes 5 and its shader ignores it (10 bounces); so does HipRenderer
 
   HipRenderer renderer;
-  renderer.referenceBounceLimit = true; // 10 bounces, like the reference shader
   if (!renderer.initialize(nullptr, WINDOW_WIDTH, WINDOW_HEIGHT)) return 1;
 
   const double aspectRatio = static_cast<double>(WINDOW_WIDTH) / WINDOW_HEIGHT;

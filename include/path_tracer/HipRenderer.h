@@ -12,9 +12,11 @@
 //     no swapchain); the frame is read back with readbackRGBA8()/readbackFloat()
 //     or written with writePPM().
 //   * present() waits for the frame instead of blitting it.
-//   * render() honours PushConstants::maxDepth unless referenceBounceLimit is
-//     set, in which case it renders 10 bounces like the reference shader, which
-//     ignores the field (reference shaders/raytrace.comp:603).
+//   * render() runs 10 bounces whatever PushConstants::maxDepth says, like the
+//     reference shader, which ignores the field (reference
+//     shaders/raytrace.comp:603); setHonourMaxDepth(true) makes maxDepth the limit.
+//   * updateScene() reports a rejected scene on std::cerr and render() then refuses to
+//     draw until a scene is accepted (the reference fails silently and draws garbage).
 //   * getOutputImage() returns the device pointer of the rgba8 frame.
 #ifndef PATH_TRACER_HIP_RENDERER_H
 #define PATH_TRACER_HIP_RENDERER_H
@@ -98,8 +100,15 @@ public:
   HipRenderer(const HipRenderer &) = delete;
   HipRenderer &operator=(const HipRenderer &) = delete;
 
-  // Reproduce the reference shader's fixed 10 bounces regardless of maxDepth.
-  bool referenceBounceLimit = false;
+  // Extension: make PushConstants::maxDepth (> 0) the bounce limit.  Off by default: the reference
+  // shader always runs 10 bounces (reference shaders/raytrace.comp:603-605).
+  void setHonourMaxDepth(bool on) {
+    honourMaxDepth_ = on;
+    if (handle_) pt_set_option(handle_, PT_OPT_HONOUR_MAX_DEPTH, on ? 1 : 0);
+  }
+  bool honourMaxDepth() const { return honourMaxDepth_; }
+  // False after an updateScene() that the library rejected (until one is accepted).
+  bool sceneOk() const { return sceneOk_; }
 
   // `window` is ignored.  Failure: false + message on std::cerr, like the reference.
   bool initialize(void *window, int width, int height, int device = 0) {
@@ -112,6 +121,8 @@ public:
     }
     width_ = width;
     height_ = height;
+    sceneOk_ = true;
+    pt_set_option(handle_, PT_OPT_HONOUR_MAX_DEPTH, honourMaxDepth_ ? 1 : 0);
     shaderPathToIndex_.clear();
     for (int i = 0; i < pt_shader_count(); ++i) shaderPathToIndex_[pt_shader_path(i)] = i + 1;
     return true;
@@ -122,29 +133,40 @@ public:
     handle_ = nullptr;
   }
 
-  // Copies the scene; may be called every frame.  Voxels are uploaded once.
-  // Failures are reported on std::cerr and leave the previous scene in place
-  // (the reference fails silently).
+  // Copies the scene; may be called every frame.  Voxels are uploaded once.  An empty vector keeps
+  // what the previous call supplied for it, as the reference's buffers do (it skips the copy of
+  // an empty vector, reference src/VulkanRenderer.cpp:824-987).  A scene the library rejects (an
+  // object without a material: SceneManager leaves index -1, which the reference shader reads out
+  // of bounds) is reported on std::cerr and blocks render() until a scene is accepted.
   void updateScene(const std::vector<GPUSphere> &spheres, const std::vector<GPUEllipsoid> &ellipsoids,
                    const std::vector<GPUMaterial> &materials, const std::vector<GPULight> &lights,
                    const std::vector<GPUVolumetricData> &volumes,
                    const std::vector<uint8_t> &voxelData = std::vector<uint8_t>()) {
     if (!handle_) return;
+    if (!spheres.empty()) spheres_ = spheres;
+    if (!ellipsoids.empty()) ellipsoids_ = ellipsoids;
+    if (!materials.empty()) materials_ = materials;
+    if (!lights.empty()) lights_ = lights;
+    if (!volumes.empty()) volumes_ = volumes;
     const int rc = pt_update_scene(
-        handle_, reinterpret_cast<const PtGPUSphere *>(spheres.data()), (int)spheres.size(),
-        reinterpret_cast<const PtGPUEllipsoid *>(ellipsoids.data()), (int)ellipsoids.size(),
-        reinterpret_cast<const PtGPUMaterial *>(materials.data()), (int)materials.size(),
-        reinterpret_cast<const PtGPULight *>(lights.data()), (int)lights.size(),
-        reinterpret_cast<const PtGPUVolumetricData *>(volumes.data()), (int)volumes.size(), voxelData.data(),
+        handle_, reinterpret_cast<const PtGPUSphere *>(spheres_.data()), (int)spheres_.size(),
+        reinterpret_cast<const PtGPUEllipsoid *>(ellipsoids_.data()), (int)ellipsoids_.size(),
+        reinterpret_cast<const PtGPUMaterial *>(materials_.data()), (int)materials_.size(),
+        reinterpret_cast<const PtGPULight *>(lights_.data()), (int)lights_.size(),
+        reinterpret_cast<const PtGPUVolumetricData *>(volumes_.data()), (int)volumes_.size(), voxelData.data(),
         voxelData.size());
-    if (rc != PT_OK) std::cerr << "HipRenderer::updateScene: " << pt_last_error() << std::endl;
+    sceneOk_ = rc == PT_OK;
+    if (!sceneOk_) std::cerr << "HipRenderer::updateScene: " << pt_last_error() << " (render() is blocked until a scene is accepted)" << std::endl;
   }
 
   // Enqueues one frame and returns.
   void render(const PushConstants &pushConstants) {
     if (!handle_) return;
-    PushConstants pc = pushConstants;
-    if (referenceBounceLimit) pc.maxDepth = 10;
+    if (!sceneOk_) {
+      std::cerr << "HipRenderer::render: the last updateScene() was rejected; nothing drawn" << std::endl;
+      return;
+    }
+    const PushConstants &pc = pushConstants;
     if (pt_render(handle_, reinterpret_cast<const PtPushConstants *>(&pc)) != PT_OK)
       std::cerr << "HipRenderer::render: " << pt_last_error() << std::endl;
   }
@@ -152,9 +174,8 @@ public:
   // Not in the reference: mean of sub-pixel samples firstSample .. firstSample + numSamples - 1
   // (sample 0 is the reference's pixel-corner sample); keep continues the previous call's sum.
   void renderSamples(const PushConstants &pushConstants, int firstSample, int numSamples, bool keep = false) {
-    if (!handle_) return;
-    PushConstants pc = pushConstants;
-    if (referenceBounceLimit) pc.maxDepth = 10;
+    if (!handle_ || !sceneOk_) return;
+    const PushConstants &pc = pushConstants;
     if (pt_render_samples(handle_, reinterpret_cast<const PtPushConstants *>(&pc), firstSample, numSamples, keep ? 1 : 0) != PT_OK)
       std::cerr << "HipRenderer::renderSamples: " << pt_last_error() << std::endl;
   }
@@ -200,6 +221,12 @@ public:
 private:
   PtRenderer *handle_ = nullptr;
   int width_ = 0, height_ = 0;
+  bool honourMaxDepth_ = false, sceneOk_ = true;
+  std::vector<GPUSphere> spheres_;
+  std::vector<GPUEllipsoid> ellipsoids_;
+  std::vector<GPUMaterial> materials_;
+  std::vector<GPULight> lights_;
+  std::vector<GPUVolumetricData> volumes_;
   std::unordered_map<std::string, int> shaderPathToIndex_;
 };
 

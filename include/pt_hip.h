@@ -49,6 +49,10 @@ enum {
                                its longest chain of dependent rays (a rank's share of a frame
                                split over many GPUs).  A caller's stream or output buffers given
                                for slot 0 only imply 1.                                           */
+  PT_OPT_HONOUR_MAX_DEPTH = 7, /* 0 (default): every frame runs 10 bounces whatever
+                               PushConstants.maxDepth says, as the reference shader does
+                               (it ignores the field, shaders/raytrace.comp:603-605);
+                               1: maxDepth > 0 is the bounce limit (an extension)       */
   PT_OPT_TILE_ORDER = 3     /* 1: a short pass before each frame sorts the 8x8 tiles so
                                that those whose pixels cast the longest chains of rays
                                are drawn first; 0: index order; 2 (default): sorted
@@ -90,9 +94,10 @@ int pt_reset_voxels(PtRenderer *r);
  * src/VulkanRenderer.cpp:1080-1145): enqueue one frame on the renderer's
  * stream and return.  The object/light/volume counts are taken from `pc` like
  * the shader does and must not exceed what pt_update_scene received.
- * `pc->maxDepth` is the bounce limit; the reference shader ignores it and
- * always uses 10 (shaders/raytrace.comp:603), so maxDepth <= 0 selects 10 and
- * a caller that wants the reference's images passes 10. */
+ * `pc->maxDepth` is ignored and the frame runs 10 bounces, exactly as the
+ * reference shader does (shaders/raytrace.comp:603-605; the reference demo
+ * passes 5 and gets 10).  With PT_OPT_HONOUR_MAX_DEPTH = 1 a positive
+ * maxDepth becomes the bounce limit. */
 int pt_render(PtRenderer *r, const PtPushConstants *pc);
 
 /* VulkanRenderer::present (reference include/VulkanRenderer.h:90): there is no

@@ -33,13 +33,30 @@ int fail(int code, const std::string &msg) {
       return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
   } while (0)
 
-// Compiled-in surface shaders in the order the reference's sorted directory
-// scan assigns indices 1, 2, ... (reference src/ShaderCompiler.cpp:93-118,131-185).
+// Compiled-in surface shaders: the rows of the registry in pt_shaders.hpp, which stand in the order the
+// reference's sorted directory scan assigns indices 1, 2, ... (reference src/ShaderCompiler.cpp:93-118,131-185).
 const char *const kShaderPaths[] = {
-    "shaders/surface_shaders/rainbow.glsl",
-    "shaders/surface_shaders/toon.glsl",
+#define PT_X(IDX, PATH, S) PATH,
+    PT_SURFACE_SHADERS(PT_X)
+#undef PT_X
 };
-constexpr int kShaderCount = 2;
+constexpr int kShaderIndices[] = {
+#define PT_X(IDX, PATH, S) IDX,
+    PT_SURFACE_SHADERS(PT_X)
+#undef PT_X
+};
+constexpr int kShaderCount = (int)(sizeof kShaderPaths / sizeof kShaderPaths[0]);
+constexpr bool shader_rows_in_order() { // row i has index i + 1 and the paths ascend as std::map<std::string, ...> orders them
+  for (int i = 0; i < kShaderCount; ++i)
+    if (kShaderIndices[i] != i + 1) return false;
+  return true;
+}
+static_assert(shader_rows_in_order(), "PT_SURFACE_SHADERS: row i must carry index i + 1");
+bool shader_paths_sorted() {
+  for (int i = 1; i < kShaderCount; ++i)
+    if (std::strcmp(kShaderPaths[i - 1], kShaderPaths[i]) >= 0) return false;
+  return true;
+}
 
 struct DevBuf {
   void *p = nullptr;
@@ -128,6 +145,7 @@ struct PtRenderer {
   int tune = 0;
   void *extRgba8[kMaxSlots] = {}, *extF32[kMaxSlots] = {}; // caller-owned output per slot (pt_set_output: slot 0, pt_set_slot)
   bool floatOutput = true;
+  bool honourMaxDepth = false; // PT_OPT_HONOUR_MAX_DEPTH
   int objectSource = 0;
 
   // row bands
@@ -197,7 +215,24 @@ void *slot_f32(const PtRenderer *r, int slot) {
   return r->floatOutput ? r->dF32[slot].p : nullptr;
 }
 
-int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: the kernel's MODE (0 plain, 1 counting, 2 phase cycles)
+// pt_render_static: the frame's scratch (ticket counters, class counts, tile-order lists) in a
+// file-scope device array instead of buffers the library allocates.  g_staticScratch is the host-side
+// stand-in of the symbol, not a device address: host code uses the per-device address that pt_create
+// fetched with hipGetSymbolAddress (every GPU holds its own copy of the array).
+constexpr int kStaticMaxTiles = 1 << 18; // 8x8-pixel tiles: frames up to 16.7 M pixels (4K has 129 600)
+constexpr size_t kStaticOrderOffset = 8192; // the counters block (kScratchBytes <= 8192) comes first
+constexpr size_t kStaticScratchBytes = kStaticOrderOffset + (size_t)3 * kStaticMaxTiles * sizeof(int);
+static_assert(kScratchBytes <= kStaticOrderOffset, "counter block outgrew its place in the static scratch");
+
+// Where a frame goes when the caller fixes everything (pt_render_static); nullptr: a frame slot of the renderer.
+struct FrameTarget {
+  hipStream_t stream;
+  void *rgba8, *f32;
+  char *scratch;  // kScratchBytes, zeroed by the launch
+  int *tileOrder; // room for 3 x kStaticMaxTiles entries
+};
+
+int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const FrameTarget *fixed = nullptr) { // mode: the kernel's MODE (0 plain, 1 counting, 2 phase cycles)
   if (!r || !pc) return fail(PT_ERR_INVALID, "pt_render: null argument");
   if (!r->sceneValid) return fail(PT_ERR_STATE, "pt_render: pt_update_scene has not been called");
   if (pc->numSpheres < 0 || pc->numSpheres > r->numSpheres || pc->numEllipsoids < 0 ||
@@ -205,10 +240,13 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
       pc->numVolumes < 0 || pc->numVolumes > r->numVolumes)
     return fail(PT_ERR_INVALID, "pt_render: push-constant object counts exceed the uploaded scene");
   PT_HIP_CHECK(hipSetDevice(r->device));
-  const int slot = (mode == 0 && pipelined(r)) ? (r->lastSlot + 1) % r->framesInFlight : 0;
-  const hipStream_t stream = r->stream[slot];
-  int rc = ensure_outputs(r, slot);
-  if (rc != PT_OK) return rc;
+  const int slot = fixed ? 0 : ((mode == 0 && pipelined(r)) ? (r->lastSlot + 1) % r->framesInFlight : 0);
+  const hipStream_t stream = fixed ? fixed->stream : r->stream[slot];
+  if (!fixed) {
+    int rc = ensure_outputs(r, slot);
+    if (rc != PT_OK) return rc;
+  }
+  char *const scratch = fixed ? fixed->scratch : (char *)r->dScratch[slot].p;
 
   ptdev::FrameParams P;
   std::memset(&P, 0, sizeof P);
@@ -238,7 +276,8 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   P.numVolumes = pc->numVolumes;
   P.numEmSpheres = r->numEmSpheres;
   P.numEmEllipsoids = r->numEmEllipsoids;
-  P.maxBounces = pc->maxDepth > 0 ? pc->maxDepth : 10;
+  // the reference shader ignores maxDepth and always runs 10 bounces (reference shaders/raytrace.comp:603)
+  P.maxBounces = (r->honourMaxDepth && pc->maxDepth > 0) ? pc->maxDepth : 10;
   P.tilesX = (r->width + ptdev::kTileDim - 1) / ptdev::kTileDim;
   int tilesY = (r->localRows + ptdev::kTileDim - 1) / ptdev::kTileDim;
   P.numTiles = P.tilesX * tilesY;
@@ -274,10 +313,10 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
     P.brickX = (r->brickRes[0] + 7) / 8;
     P.brickY = (r->brickRes[1] + 7) / 8;
   }
-  P.outRgba8 = (uint32_t *)slot_rgba8(r, slot);
-  P.outF32 = (float4 *)slot_f32(r, slot);
-  P.tileCounter = (unsigned int *)((char *)r->dScratch[slot].p + 512);
-  P.counters = (unsigned long long *)((char *)r->dScratch[slot].p + 64);
+  P.outRgba8 = (uint32_t *)(fixed ? fixed->rgba8 : slot_rgba8(r, slot));
+  P.outF32 = (float4 *)(fixed ? fixed->f32 : slot_f32(r, slot));
+  P.tileCounter = (unsigned int *)(scratch + 512);
+  P.counters = (unsigned long long *)(scratch + 64);
 
   if (P.numTiles <= 0) return PT_OK;
   // The ordering pass pays off when pixels differ a lot in the number of rays
@@ -286,10 +325,17 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
       r->tileOrder == 1 ||
       (r->tileOrder == 2 && r->sceneBounces && P.maxBounces > 1 &&
        (long long)(pc->numSpheres + pc->numEllipsoids) * P.numTiles <= 50000000ll);
+  if (fixed && P.numTiles > kStaticMaxTiles)
+    return fail(PT_ERR_INVALID, "pt_render_static: the frame has " + std::to_string(P.numTiles) + " tiles of 8x8 pixels, the static scratch holds " +
+                                    std::to_string(kStaticMaxTiles));
   if (orderTiles) {
-    PT_HIP_CHECK(r->dTileOrder[slot].reserve((size_t)P.numTiles * 3 * sizeof(int)));
-    P.tileOrder = (int *)r->dTileOrder[slot].p;
-    P.classCount = (unsigned int *)((char *)r->dScratch[slot].p + 16);
+    if (fixed) {
+      P.tileOrder = fixed->tileOrder;
+    } else {
+      PT_HIP_CHECK(r->dTileOrder[slot].reserve((size_t)P.numTiles * 3 * sizeof(int)));
+      P.tileOrder = (int *)r->dTileOrder[slot].p;
+    }
+    P.classCount = (unsigned int *)(scratch + 16);
   }
 
   // Launch geometry: persistent workgroups, 16 waves per CU.  Objects are
@@ -310,7 +356,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   size_t ldsBytes = objBytes + (size_t)(threads / 64) * 1024 + ((sizeof(ptdev::FrameParams) + 15) & ~(size_t)15) + 1024; // + the kernel's copy of the frame constants + its b/255 table
   // Pooled tracing at the end of the frame pays when one pass over the spheres is long.
   {
-    const size_t coopBytes = 64 + (size_t)threads * (6 * sizeof(float) + sizeof(unsigned long long)) +
+    const size_t coopBytes = 64 + (size_t)threads * (6 * sizeof(float) + 2 * sizeof(unsigned long long)) + // result slots: one set per pass parity
                              (size_t)(threads / 4) * (7 * sizeof(float) + sizeof(unsigned long long)); // pooled rays + exact-routine rays
     const bool fits = ldsBytes + coopBytes <= 160 * 1024 / (size_t)blocksPerCu;
     P.coop = (pc->numSpheres >= 256 && fits && !(r->tune & 16)) ? 1 : 0;
@@ -326,7 +372,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   P.ellScale = r->ellScale;
   P.volumeFilter = r->volumeFilter;
   P.sampleIndex = r->sampleIndex;
-  if (r->accumulate) {
+  if (r->accumulate && !fixed) {
     PT_HIP_CHECK(r->dAccum.reserve((size_t)r->width * (size_t)std::max(r->localRows, 1) * sizeof(float4)));
     P.accum = (float4 *)r->dAccum.p;
     P.accumCount = r->accumCount + 1;
@@ -349,7 +395,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
   int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
 
-  PT_HIP_CHECK(hipMemsetAsync(r->dScratch[slot].p, 0, kScratchBytes, stream));
+  PT_HIP_CHECK(hipMemsetAsync(scratch, 0, kScratchBytes, stream));
   if (P.tileOrder) {
     const size_t stage = ((size_t)pc->numSpheres + 4 * (size_t)pc->numEllipsoids) * sizeof(float4);
     if (stage <= 48 * 1024)
@@ -376,7 +422,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode) { // mode: 
 #undef PT_LAUNCH
 #undef PT_LAUNCH_K
   PT_HIP_CHECK(hipGetLastError());
-  r->lastSlot = slot;
+  if (!fixed) r->lastSlot = slot;
   r->lastBlocks = blocks;
   r->lastThreads = threads;
   r->lastLds = (int)ldsBytes;
@@ -400,6 +446,7 @@ int pt_create(int width, int height, int device, PtRenderer **out) {
   *out = nullptr;
   if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 30))
     return fail(PT_ERR_INVALID, "pt_create: bad frame size");
+  if (!shader_paths_sorted()) return fail(PT_ERR_STATE, "pt_create: the surface-shader registry is not in sorted path order");
   int nDev = 0;
   PT_HIP_CHECK(hipGetDeviceCount(&nDev));
   if (device < 0 || device >= nDev) return fail(PT_ERR_INVALID, "pt_create: no such HIP device");
@@ -417,8 +464,13 @@ int pt_create(int width, int height, int device, PtRenderer **out) {
   std::snprintf(r->deviceName, sizeof r->deviceName, "%s (%s)", prop.name, prop.gcnArchName);
   int rc = ensure_slots(r, r->framesInFlight);
   if (rc != PT_OK) { pt_destroy(r); return rc; }
-  (void)hipEventCreate(&r->evBegin);
-  (void)hipEventCreate(&r->evEnd);
+  for (hipEvent_t *ev : {&r->evBegin, &r->evEnd}) {
+    e = hipEventCreate(ev);
+    if (e != hipSuccess) {
+      pt_destroy(r);
+      return fail(PT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+    }
+  }
   rc = ensure_outputs(r, 0);
   if (rc != PT_OK) { pt_destroy(r); return rc; }
   *out = r;
@@ -654,18 +706,27 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     r->volume0 = volumes[0];
     size_t need = (size_t)volumes[0].resolution_x * volumes[0].resolution_y * volumes[0].resolution_z;
     if (voxels && voxel_bytes > 0 && !r->voxelsUploaded) {
-      // Uploaded once (reference src/VulkanRenderer.cpp:961-987).  Voxels the
-      // file did not supply read as 0.
-      PT_HIP_CHECK(r->dVoxels.reserve(need + 16));
-      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream[0]));
-      PT_HIP_CHECK(hipMemcpyAsync(r->dVoxels.p, voxels, std::min(need, voxel_bytes), hipMemcpyHostToDevice, r->stream[0]));
+      // Uploaded once (reference src/VulkanRenderer.cpp:961-987).  All of the caller's bytes are kept: the
+      // reference keeps the file's bytes and indexes them with whatever resolution the current scene
+      // states.  Voxels the file did not supply read as 0.
+      const size_t cap = std::max(need, voxel_bytes);
+      PT_HIP_CHECK(r->dVoxels.reserve(cap + 16));
+      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, cap + 16, r->stream[0]));
+      PT_HIP_CHECK(hipMemcpyAsync(r->dVoxels.p, voxels, voxel_bytes, hipMemcpyHostToDevice, r->stream[0]));
       r->voxelsUploaded = true;
-      r->voxelBytes = need;
+      r->voxelBytes = cap;
       r->brickRes[0] = 0; // rebuild the bricked copy
     } else if (!r->voxelsUploaded || r->voxelBytes < need) {
-      // A volume without data marches through zeros.
-      PT_HIP_CHECK(r->dVoxels.reserve(need + 16));
-      PT_HIP_CHECK(hipMemsetAsync(r->dVoxels.p, 0, need + 16, r->stream[0]));
+      // A volume without data marches through zeros; a volume whose resolution outgrows what was
+      // uploaded keeps the uploaded bytes (re-indexed, as in the reference) and reads zeros beyond them.
+      DevBuf bigger;
+      PT_HIP_CHECK(bigger.reserve(need + 16));
+      PT_HIP_CHECK(hipMemsetAsync(bigger.p, 0, need + 16, r->stream[0]));
+      if (r->voxelsUploaded && r->dVoxels.p && r->voxelBytes > 0)
+        PT_HIP_CHECK(hipMemcpyAsync(bigger.p, r->dVoxels.p, r->voxelBytes, hipMemcpyDeviceToDevice, r->stream[0]));
+      PT_HIP_CHECK(hipStreamSynchronize(r->stream[0]));
+      r->dVoxels.release();
+      r->dVoxels = bigger;
       r->voxelBytes = need;
       r->brickRes[0] = 0;
     }
@@ -843,7 +904,7 @@ int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
   int maxLocal = compute_local_rows(r->height, band_rows, 0, band_count);
   if (stride_rows < maxLocal) return fail(PT_ERR_INVALID, "pt_assemble_bands: stride_rows smaller than a rank's frame");
   PT_HIP_CHECK(hipSetDevice(r->device));
-  dim3 block(256), grid((r->width + 255) / 256, r->height);
+  dim3 block(256), grid((r->width + 255) / 256, std::min(r->height, 65535)); // the kernel strides over rows
   const hipStream_t astream = r->stream[r->lastSlot]; // behind the frame just drawn
   if (elem_bytes == 4)
     hipLaunchKernelGGL((ptdev::pt_assemble_bands_kernel<uint32_t>), grid, block, 0, astream, (const uint32_t *)src,
@@ -875,6 +936,9 @@ int pt_set_slot(PtRenderer *r, int slot, void *hip_stream, void *rgba8_dev, void
 int pt_set_output(PtRenderer *r, void *rgba8_dev, void *f32_dev) {
   if (!r) return fail(PT_ERR_INVALID, "pt_set_output: renderer is null");
   if (!rgba8_dev && f32_dev) return fail(PT_ERR_INVALID, "pt_set_output: a float frame needs an rgba8 frame too");
+  // a frame in flight keeps writing the buffers it was launched with, and readback names slot 0's current ones
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
   r->extRgba8[0] = rgba8_dev;
   r->extF32[0] = f32_dev;
   return PT_OK;
@@ -938,6 +1002,7 @@ int pt_set_option(PtRenderer *r, int option, int value) {
     if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_TILE_ORDER takes 0, 1 or 2");
     r->tileOrder = value;
     return PT_OK;
+  case PT_OPT_HONOUR_MAX_DEPTH: r->honourMaxDepth = value != 0; return PT_OK;
   case 100: r->tune = value; return PT_OK; // tuning switches, see PtRenderer::tune
   case PT_OPT_OBJECT_SOURCE:
     if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "pt_set_option: object source must be 0, 1 or 2");

@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include "pt_frame.hpp"
+#include "pt_shaders.hpp"
 
 namespace ptdev {
 
@@ -46,7 +47,7 @@ enum : int {
   ST_IDLE = 0,       // wants a pixel
   ST_PATH = 1,       // primary / bounce ray, closest hit        (raytrace.comp:610)
   ST_LIGHT = 2,      // getShadowFactor for light k, Phong        (raytrace.comp:345)
-  ST_TOON_LIGHT = 3, // getShadowFactor for light k, toon shader  (toon.glsl:19)
+  ST_SHADER_LIGHT = 3, // getShadowFactor for light k, in a surface shader's light loop (toon.glsl:19)
   ST_EM_SPHERE = 4,  // emissive-sphere occlusion ray             (raytrace.comp:431)
   ST_EM_ELLIPSOID = 5, // emissive-ellipsoid occlusion ray        (raytrace.comp:469)
   ST_JOB = 6,        // a shadow / occlusion ray cast on behalf of another lane (fan-out, see the kernel)
@@ -118,7 +119,12 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
 #define PT_CTRL_LOAD(i) __hip_atomic_load(&c_ctrl[(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define PT_CTRL_STORE(i, v) __hip_atomic_store(&c_ctrl[(i)], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
   float *const c_rays = (float *)(coopBase + 64);
-  unsigned long long *const c_slot = (unsigned long long *)(coopBase + 64 + 6 * sizeof(float) * (size_t)nThreads);
+  // Result slots of the pooled rays, one set per pass parity: a wave reads its results after the pass's second
+  // barrier, and nothing orders that read against a faster wave's slot initialisation for the next pass (which
+  // comes before that pass's first barrier), so consecutive passes must not share slots.  The other pooled
+  // arrays are only touched between a pass's two barriers, or written after its second and read after the
+  // next pass's first: the barriers order those.
+  unsigned long long *const c_slot2 = (unsigned long long *)(coopBase + 64 + 6 * sizeof(float) * (size_t)nThreads);
   if (poolingOn && threadIdx.x < 8) PT_CTRL_STORE(threadIdx.x, 0);
   __syncthreads(); // the table and the control words are in place
   bool coop = false; // wave-uniform: this wave has joined the pooled mode
@@ -558,6 +564,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         // proportion to the rays that are left instead of one full sphere loop
         // per wave that still holds a ray.
         const int par = coopPass & 1;
+        unsigned long long *const c_slot = c_slot2 + (size_t)par * nThreads;
         ++coopPass;
         if (PHASES && waveInBlock == 0) nPooled++;
         if (ballot64(live) != 0ull && lane == 0) PT_CTRL_STORE(3 + par, 1);
@@ -575,7 +582,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         // finite rays for the exact routine go to a second list (up to nThreads / 4 of them)
         const int xCap = nThreads >> 2;
-        float *const c_xrays = (float *)(c_slot + nThreads);
+        float *const c_xrays = (float *)(c_slot2 + 2 * nThreads);
         unsigned long long *const c_xslot = (unsigned long long *)(c_xrays + 7 * xCap);
         {
           const bool want = special && qLane;
@@ -845,9 +852,20 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     //    its next ray or finished its pixel
     // ------------------------------------------------------------------
     // Labels of the per-lane coroutine.  `step` says where to resume.
-    enum { GO_PATH_RESULT, GO_NEXT_LIGHT, GO_NEXT_TOON_LIGHT, GO_NEXT_EM_SPHERE, GO_NEXT_EM_ELLIPSOID,
+    enum { GO_PATH_RESULT, GO_NEXT_LIGHT, GO_NEXT_SHADER_LIGHT, GO_NEXT_EM_SPHERE, GO_NEXT_EM_ELLIPSOID,
            GO_AFTER_LIGHTING, GO_FINISH, GO_EMITTED };
     const bool hitAny = bestIdx >= 0;
+
+    // SurfaceShaderData of the hit being shaded (raytrace.comp:298-309), and its material's shader index.
+    auto shaderDataAtHit = [&](int &shaderIndex) -> SurfaceShaderData {
+      const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1), m2 = PT_MAT(hitMat, 2);
+      SurfaceShaderData data;
+      data.hitPoint = hitP; data.normal = hitN; data.viewDir = viewDir; data.surfaceColor = xyz(m0);
+      data.ambient = m0.w; data.diffuse = m1.x; data.specular = m1.y; data.shininess = m1.z;
+      data.emissiveStrength = m2.y; data.time = L.time; data.materialIndex = hitMat;
+      shaderIndex = (int)m2.z;
+      return data;
+    };
 
     // What calculateLighting does with the outcome of one shadow / occlusion ray: `kind` is the
     // lane state the ray was cast in, kk its light index, (dir, range) the ray, pend the
@@ -870,22 +888,16 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float specularStrength = highlight_pow(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
         const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularStrength), attenuation);
         lit = add3(lit, add3(diffuse, specular));
-      } else if (kind == ST_TOON_LIGHT) {
-        // toon.glsl:22-39
+      } else if (kind == ST_SHADER_LIGHT) {
+        // the body of the shader's light loop for a light that is not shadowed (toon.glsl:22-39)
         const float4 Lt = PT_LIGHT(kk);
-        const float4 m0 = PT_MAT(hitMat, 0), m1 = PT_MAT(hitMat, 1);
-        const V3 surfaceColor = xyz(m0);
-        const float distance = range; // as above (toon.glsl:19 vs :22-25)
-        const V3 lightDir = dir;
-        const float attenuation = Lt.w / ((1.0f + 0.09f * distance) + (0.032f * distance) * distance);
-        const float diffuseRaw = glmax(0.0f, dot3(hitN, lightDir));
-        const float diffuseQuantized = diffuseRaw > 0.6f ? 1.0f : (diffuseRaw > 0.3f ? 0.5f : 0.0f);
-        const V3 diffuse = scale3(scale3(surfaceColor, m1.x * diffuseQuantized), attenuation);
-        const V3 halfDir = normalize3(add3(lightDir, viewDir));
-        const float specularRaw = highlight_pow(glmax(0.0f, dot3(hitN, halfDir)), m1.z);
-        const float specularQuantized = specularRaw > 0.8f ? 1.0f : 0.0f;
-        const V3 specular = scale3(scale3(scale3(surfaceColor, m1.y), specularQuantized), attenuation);
-        lit = add3(lit, add3(diffuse, specular));
+        int shaderIndex;
+        const SurfaceShaderData data = shaderDataAtHit(shaderIndex);
+        SurfaceShaderResult res;
+        res.color = lit; res.emissive = mk3(0, 0, 0); res.emissiveStrength = data.emissiveStrength;
+        // lightDir and distance are the shadow ray's direction and range (toon.glsl:19 vs :22-25)
+        res = shader_light(shaderIndex, data, res, dir, range, Lt.w);
+        lit = res.color;
       } else { // ST_EM_SPHERE, ST_EM_ELLIPSOID: raytrace.comp:433-440, 471-477
         lit = add3(lit, pend);
       }
@@ -896,7 +908,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // hit point (:367-480, over the precomputed emissive lists).  Leaves `step` at
     // GO_EMITTED with the ray in (rO, rD, rTmax) or at the step after the lighting.
     auto nextLightingRay = [&](int &step) {
-      if (step == GO_NEXT_LIGHT || step == GO_NEXT_TOON_LIGHT) do {
+      if (step == GO_NEXT_LIGHT || step == GO_NEXT_SHADER_LIGHT) do {
         if (k < L.numLights) { // getShadowFactor (:243-253)
           const float4 L = PT_LIGHT(k);
           const V3 lightVec = sub3(xyz(L), hitP);
@@ -904,18 +916,19 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           rO = hitP;
           rD = div3s(lightVec, distToLight);
           rTmax = distToLight;
-          state = (step == GO_NEXT_LIGHT) ? ST_LIGHT : ST_TOON_LIGHT;
+          state = (step == GO_NEXT_LIGHT) ? ST_LIGHT : ST_SHADER_LIGHT;
           if (COUNT) cLight++;
           step = GO_EMITTED;
         } else if (step == GO_NEXT_LIGHT) {
           k = 0;
           step = GO_NEXT_EM_SPHERE;
-        } else { // toon.glsl:42-47: result.color + result.emissive
-          const float4 m0 = PT_MAT(hitMat, 0);
-          const float4 m2 = PT_MAT(hitMat, 2);
-          V3 em = mk3(0, 0, 0);
-          if (m2.y > 0.0f) em = scale3(xyz(m0), m2.y);
-          lit = add3(lit, em);
+        } else { // after the shader's light loop (toon.glsl:42-47), then result.color + result.emissive (raytrace.comp:324)
+          int shaderIndex;
+          const SurfaceShaderData data = shaderDataAtHit(shaderIndex);
+          SurfaceShaderResult res;
+          res.color = lit; res.emissive = mk3(0, 0, 0); res.emissiveStrength = data.emissiveStrength;
+          res = shader_end(shaderIndex, data, res);
+          lit = add3(res.color, res.emissive);
           step = GO_AFTER_LIGHTING;
         }
       } while (0);
@@ -932,19 +945,25 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const V3 dirToSphere = div3s(toSphere, distToSphere);
           const int sphereShaderIndex = __float_as_int(sx.x);
           bool skip = false;
-          if (sphereShaderIndex != 0) { // :377-414
-            const V3 approximateHitPoint = sub3(xyz(s), scale3(dirToSphere, s.w));
-            if (sphereShaderIndex == 1) {
-              emissiveColor = rainbow_emissive(approximateHitPoint, sphereEmissive, L.time);
-            } else if (sphereShaderIndex == 2) {
-              // toon keeps result.emissive = surfaceColor * emissiveStrength (toon.glsl:45-47);
-              // its light loop only feeds result.color, which this caller drops, so the
-              // shadow rays it would issue are elided (but still counted as issued)
-              emissiveColor = scale3(xyz(sm), sphereEmissive);
-              if (COUNT) { cLight += (unsigned int)L.numLights; cRays += (unsigned int)L.numLights; }
-            } else {
-              emissiveColor = mk3(0, 0, 0);
-            }
+          if (sphereShaderIndex != 0) { // :377-414: the sphere's shader gives the emissive colour and strength
+            const int sphereMat = PT_MATIDX(si);
+            const float4 q0 = PT_MAT(sphereMat, 0), q1 = PT_MAT(sphereMat, 1);
+            SurfaceShaderData data;
+            data.hitPoint = sub3(xyz(s), scale3(dirToSphere, s.w)); // approximateHitPoint
+            data.normal = neg3(dirToSphere);
+            data.viewDir = dirToSphere;
+            data.surfaceColor = xyz(q0);
+            data.ambient = q0.w; data.diffuse = q1.x; data.specular = q1.y; data.shininess = q1.z;
+            data.emissiveStrength = sphereEmissive; data.time = L.time; data.materialIndex = sphereMat;
+            SurfaceShaderResult res;
+            res.color = mk3(0, 0, 0); res.emissive = mk3(0, 0, 0); res.emissiveStrength = sphereEmissive;
+            res = shader_begin(sphereShaderIndex, data, res);
+            // A light loop only feeds result.color, which this caller drops: its shadow rays are not
+            // cast (but counted as issued, since the shader function would cast them).
+            if (COUNT && shader_has_light_loop(sphereShaderIndex)) { cLight += (unsigned int)L.numLights; cRays += (unsigned int)L.numLights; }
+            res = shader_end(sphereShaderIndex, data, res);
+            emissiveColor = res.emissive;
+            sphereEmissive = res.emissiveStrength;
             if (length3(emissiveColor) < 0.001f) skip = true;
           }
           if (!skip) {
@@ -1021,7 +1040,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         applyResult(state, k, hitAny, rD, rTmax, pending);
         k++;
         step = state == ST_LIGHT ? GO_NEXT_LIGHT
-               : state == ST_TOON_LIGHT ? GO_NEXT_TOON_LIGHT
+               : state == ST_SHADER_LIGHT ? GO_NEXT_SHADER_LIGHT
                : state == ST_EM_SPHERE ? GO_NEXT_EM_SPHERE : GO_NEXT_EM_ELLIPSOID;
       }
 
@@ -1218,16 +1237,19 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           // calculateLighting (:286-336)
           if (COUNT) cShaded++;
           const int shaderFunctionIndex = (int)m2.z;
-          if (shaderFunctionIndex != 0) {
-            if (shaderFunctionIndex == 1) { // rainbow: color 0 + emissive
-              lit = add3(mk3(0, 0, 0), rainbow_emissive(hitP, emissiveStrength, L.time));
-              step = GO_AFTER_LIGHTING;
-            } else if (shaderFunctionIndex == 2) { // toon.glsl:11
-              lit = scale3(surfaceColor, m0.w);
+          if (shaderFunctionIndex != 0) { // :297-326, dispatch through the shader registry
+            int shaderIndex;
+            const SurfaceShaderData data = shaderDataAtHit(shaderIndex);
+            SurfaceShaderResult res;
+            res.color = mk3(0, 0, 0); res.emissive = mk3(0, 0, 0); res.emissiveStrength = emissiveStrength;
+            res = shader_begin(shaderFunctionIndex, data, res);
+            if (shader_has_light_loop(shaderFunctionIndex)) { // resumed once per light, then shader_end
+              lit = res.color;
               k = 0;
-              step = GO_NEXT_TOON_LIGHT;
-            } else { // no branch of the generated chain matches: color 0 + emissive 0
-              lit = mk3(0, 0, 0);
+              step = GO_NEXT_SHADER_LIGHT;
+            } else {
+              res = shader_end(shaderFunctionIndex, data, res);
+              lit = add3(res.color, res.emissive);
               step = GO_AFTER_LIGHTING;
             }
           } else {
@@ -1301,7 +1323,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // moves on to its next one, as long as idle lanes remain to take the records; it traces the
     // last ray itself.  Next pass the helpers report hit or miss and the lane applies the
     // results in casting order, which keeps every sum in the order the shader forms it.
-    // (Toon lanes stay sequential: their last step adds to the sum before the results are in.)
+    // (Lanes inside a surface shader's light loop stay sequential: the shader's end() adds to the sum before the results are in.)
     if (fanOutOn && exhausted) {
       const unsigned long long idleNow = ballot64(state == ST_IDLE);
       bool gen = state == ST_LIGHT || state == ST_EM_SPHERE || state == ST_EM_ELLIPSOID;

@@ -239,13 +239,14 @@ template <typename T>
 __global__ void pt_assemble_bands_kernel(const T *__restrict__ src, T *__restrict__ dst, int width, int height,
                                          int bandRows, int bandCount, int strideRows) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int gy = blockIdx.y;
-  if (x >= width || gy >= height) return;
-  const int band = gy / bandRows;
-  const int owner = band % bandCount;
-  const int localBand = band / bandCount;
-  const int ly = localBand * bandRows + (gy - band * bandRows);
-  dst[(size_t)gy * width + x] = src[((size_t)owner * strideRows + ly) * width + x];
+  if (x >= width) return;
+  for (int gy = blockIdx.y; gy < height; gy += gridDim.y) { // grid.y is capped at 65535
+    const int band = gy / bandRows;
+    const int owner = band % bandCount;
+    const int localBand = band / bandCount;
+    const int ly = localBand * bandRows + (gy - band * bandRows);
+    dst[(size_t)gy * width + x] = src[((size_t)owner * strideRows + ly) * width + x];
+  }
 }
 
 } // namespace ptdev

@@ -1,5 +1,5 @@
 // pt_math.hpp — float3 / packed-pair arithmetic of the device code, with the operation
-// order the numerics contract fixes (see pt_device.hpp), and the compiled-in surface shaders.
+// order the numerics contract fixes (see pt_device.hpp).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -66,36 +66,6 @@ __device__ __forceinline__ P3 rotate_qp(P3 v, P3 q, P3 q2, f2 qw) {
 __device__ __forceinline__ V3 rotate_q(V3 v, V3 q, V3 q2, float qw) {
   V3 t = cross3(q2, v);
   return add3(madd3(v, qw, t), cross3(q, t));
-}
-
-// ---- surface shaders (compiled-in; index = position in the sorted path list + 1) ----
-
-// rainbow.glsl:1-8
-__device__ __forceinline__ float hue2rgb(float p, float q, float t) {
-  if (t < 0.0f) t += 1.0f;
-  if (t > 1.0f) t -= 1.0f;
-  if (t < 1.0f / 6.0f) return p + ((q - p) * 6.0f) * t;
-  if (t < 0.5f) return q;
-  if (t < 2.0f / 3.0f) return p + ((q - p) * (2.0f / 3.0f - t)) * 6.0f;
-  return p;
-}
-// rainbow.glsl:10-22
-__device__ __forceinline__ V3 hsl2rgb(float h, float s, float l) {
-  float H = glfract(h);
-  float S = glclamp(s, 0.0f, 1.0f);
-  float L = glclamp(l, 0.0f, 1.0f);
-  if (S == 0.0f) return mk3(L, L, L);
-  float q = (L < 0.5f) ? (L * (1.0f + S)) : ((L + S) - L * S);
-  float p = 2.0f * L - q;
-  return mk3(hue2rgb(p, q, H + 1.0f / 3.0f), hue2rgb(p, q, H), hue2rgb(p, q, H - 1.0f / 3.0f));
-}
-// rainbow.glsl:24-50 — returns result.emissive (result.color is 0)
-__device__ __attribute__((noinline)) V3 rainbow_emissive(V3 hitPoint, float emissiveStrength, float time) {
-  V3 sweepDir = normalize3(mk3(1.0f, 0.5f, 0.25f));
-  float phase = dot3(hitPoint, sweepDir) * 2.0f + time * 0.002f;
-  float cosVal = cosf(phase);
-  float hue = glfract(0.5f + 0.5f * cosVal);
-  return scale3(hsl2rgb(hue, 1.0f, 0.5f), emissiveStrength);
 }
 
 // pow(x, y) as GLSL's pow in calculateLighting and the toon shader (raytrace.comp:357, toon.glsl:33),

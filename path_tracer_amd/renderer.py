@@ -29,10 +29,8 @@ class HipRenderer:
         self._lib = None
         self.width = 0
         self.height = 0
-        # The reference shader ignores PushConstants.maxDepth and always runs 10
-        # bounces (reference shaders/raytrace.comp:603).  True reproduces that;
-        # False makes render() honour maxDepth.
-        self.reference_bounce_limit = False
+        self._honour_max_depth = False
+        self._kept = {}
 
     # -- VulkanRenderer::initialize(window, width, height); no window here
     def initialize(self, width: int, height: int, device: int = 0) -> bool:
@@ -47,7 +45,21 @@ class HipRenderer:
             return False
         self._h = h
         self.width, self.height = width, height
+        self.setOption(7, 1 if self._honour_max_depth else 0)
         return True
+
+    # The reference shader ignores PushConstants.maxDepth and always runs 10 bounces
+    # (reference shaders/raytrace.comp:603-605), and so does render() by default.
+    # honour_max_depth = True is an extension: maxDepth > 0 becomes the bounce limit.
+    @property
+    def honour_max_depth(self) -> bool:
+        return self._honour_max_depth
+
+    @honour_max_depth.setter
+    def honour_max_depth(self, on: bool) -> None:
+        self._honour_max_depth = bool(on)
+        if self._h:
+            self.setOption(7, 1 if on else 0)  # PT_OPT_HONOUR_MAX_DEPTH
 
     # -- VulkanRenderer::shutdown (idempotent)
     def shutdown(self) -> None:
@@ -68,21 +80,23 @@ class HipRenderer:
 
     # -- VulkanRenderer::updateScene(spheres, ellipsoids, materials, lights, volumes, voxelData = {})
     def updateScene(self, spheres, ellipsoids, materials, lights, volumes, voxelData=None) -> None:
+        # An empty (or None) array keeps what the previous call supplied for it: the reference skips
+        # the copy of an empty vector and its buffer keeps the old records
+        # (reference src/VulkanRenderer.cpp:801,850,876,910,936).
         arrs = []
-        for a, dt in ((spheres, T.GPU_SPHERE), (ellipsoids, T.GPU_ELLIPSOID), (materials, T.GPU_MATERIAL),
-                      (lights, T.GPU_LIGHT), (volumes, T.GPU_VOLUME)):
+        for key, a, dt in (("s", spheres, T.GPU_SPHERE), ("e", ellipsoids, T.GPU_ELLIPSOID), ("m", materials, T.GPU_MATERIAL),
+                           ("l", lights, T.GPU_LIGHT), ("v", volumes, T.GPU_VOLUME)):
             a = np.zeros(0, dt) if a is None else np.ascontiguousarray(a, dtype=dt)
-            arrs.append(a)
+            if len(a):
+                self._kept[key] = a
+            arrs.append(self._kept.get(key, a))
         vox = None if voxelData is None else np.ascontiguousarray(voxelData, dtype=np.uint8)
         _lib.check(self._lib.pt_update_scene(
             self._h, _ptr(arrs[0]), len(arrs[0]), _ptr(arrs[1]), len(arrs[1]), _ptr(arrs[2]), len(arrs[2]),
             _ptr(arrs[3]), len(arrs[3]), _ptr(arrs[4]), len(arrs[4]), _ptr(vox), 0 if vox is None else vox.size))
 
     def _pc(self, pushConstants) -> np.ndarray:
-        pc = np.array(pushConstants, dtype=T.PUSH_CONSTANTS, copy=True).reshape(())
-        if self.reference_bounce_limit:
-            pc["maxDepth"] = 10
-        return pc
+        return np.array(pushConstants, dtype=T.PUSH_CONSTANTS, copy=True).reshape(())
 
     # -- VulkanRenderer::render(pushConstants): asynchronous
     def render(self, pushConstants) -> None:
@@ -94,7 +108,11 @@ class HipRenderer:
         _lib.check(self._lib.pt_present(self._h))
 
     # ---- beyond the reference interface ----
-    def setScene(self, scene) -> None:
+    def setScene(self, scene, honour_max_depth: bool = True) -> None:
+        """Upload a ``scenes.Scene``.  The named configurations state a bounce depth
+        (``scene.max_depth``), so by default this also switches the renderer to honouring
+        ``maxDepth``; ``honour_max_depth=False`` keeps the reference's fixed 10 bounces."""
+        self.honour_max_depth = honour_max_depth
         self.updateScene(scene.spheres, scene.ellipsoids, scene.materials, scene.lights, scene.volumes, scene.voxels)
 
     def resetVoxels(self) -> None:
@@ -175,13 +193,14 @@ class HipRenderer:
 
 
 def render_scene(scene, device: int = 0, counted: bool = False, reference_bounce_limit: bool = False):
-    """Convenience: one frame of ``scene`` -> (rgba8, f32[, counters])."""
+    """Convenience for the named configurations, which state a bounce depth: one frame of ``scene``
+    with ``scene.max_depth`` honoured -> (rgba8, f32[, counters]).  ``reference_bounce_limit=True``
+    draws it the way HipRenderer does by default (10 bounces, maxDepth ignored)."""
     r = HipRenderer()
     if not r.initialize(scene.width, scene.height, device):
         raise RuntimeError("HipRenderer.initialize failed")
     try:
-        r.reference_bounce_limit = reference_bounce_limit
-        r.setScene(scene)
+        r.setScene(scene, honour_max_depth=not reference_bounce_limit)
         pc = scene.push_constants()
         r.render(pc)
         r.present()

@@ -159,3 +159,32 @@ def test_frames_in_flight_show_the_latest_frame(in_flight):
     r.render(pcs[3])
     np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[3].view(np.uint32))
     r.shutdown()
+
+
+def test_a_larger_resolution_later_keeps_the_uploaded_voxels(oracle):
+    """The reference uploads the voxel bytes once and indexes them with whatever resolution the current
+    scene states (reference src/VulkanRenderer.cpp:961-987); a later update that states a larger
+    resolution must still see those bytes (and zeros beyond them), with or without the voxels passed again."""
+    from path_tracer_amd import HipRenderer
+
+    small, big = (20, 16, 12), (24, 20, 16)
+    vox = scenes.synthetic_walnut(small)
+    sc_small = scenes.config4(160, 90, voxels=vox, resolution=small)
+    sc_big = scenes.config4(160, 90, voxels=vox, resolution=big)  # same bytes, re-indexed; the tail reads as 0
+    padded = np.zeros(big[0] * big[1] * big[2], np.uint8)
+    padded[:vox.size] = vox
+    want = oracle.render(scenes.config4(160, 90, voxels=padded, resolution=big), nthreads=8)
+    for resend in (True, False):
+        r = HipRenderer()
+        assert r.initialize(160, 90)
+        r.setScene(sc_small)
+        r.render(sc_small.push_constants()); r.present()
+        r.updateScene(sc_big.spheres, sc_big.ellipsoids, sc_big.materials, sc_big.lights, sc_big.volumes,
+                      vox if resend else None)
+        cnt = r.renderCounted(sc_big.push_constants())
+        r.render(sc_big.push_constants()); r.present()
+        got = r.readbackF32()
+        r.shutdown()
+        np.testing.assert_array_equal(cnt[:10], want[2][:10])
+        np.testing.assert_array_equal(got.view(np.uint32), want[1].view(np.uint32))
+        assert got[..., :3].max() > 0 and (got[..., :3] != got[0, 0, :3]).any()  # the volume is visible

@@ -119,6 +119,15 @@ def test_bounce_limit_is_honoured_and_reference_literal(oracle):
     ref10 = oracle.render(sc, max_bounces=10, nthreads=8)
     np.testing.assert_array_equal(gpu10[2][:NA], ref10[2][:NA])
     assert int(gpu10[2][1]) > int(gpu3[2][1])
+    # the reference's own interface (updateScene + render) ignores maxDepth like the reference shader does
+    from path_tracer_amd import HipRenderer
+
+    r = HipRenderer()
+    assert r.initialize(sc.width, sc.height)
+    r.updateScene(sc.spheres, sc.ellipsoids, sc.materials, sc.lights, sc.volumes)
+    cnt = r.renderCounted(sc.push_constants())  # maxDepth = 3 in the push constants
+    r.shutdown()
+    np.testing.assert_array_equal(cnt[:NA], ref10[2][:NA])
 
 
 def test_row_bands_reassemble_to_the_full_frame(oracle):
