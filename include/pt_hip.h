@@ -147,6 +147,23 @@ int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
  * the PT_CNT_* work counters. */
 int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters);
 
+/* pt_render without any allocation.  No counterpart in the reference; it is for
+ * callers that cannot call hipMalloc where they render: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation.  Draws the
+ * frame of `pc` into the caller's device buffers (rgba8_dev: width*rows*4 bytes,
+ * required; f32_dev: width*rows*16 bytes or NULL) on the caller's stream (NULL:
+ * the renderer's own), with the uploaded scene of `r`.  The frame's scratch
+ * (tile-ticket counters, cost-class counts, tile drawing-order lists) lives in a
+ * static device array of 3 MiB + 8 KiB that every GPU the library runs on holds
+ * until the process ends; a frame of more than 2^18 8x8-pixel tiles (16.7 M pixels)
+ * is rejected with PT_ERR_INVALID.  The call allocates nothing, waits for nothing
+ * and does not touch the renderer's frame slots (pt_readback_* and pt_device_*
+ * keep showing the last pt_render frame).  All renderers on one GPU share that
+ * GPU's array: calls that overlap on one GPU (two streams, two renderers, two
+ * threads) race; order them on one stream or with events.  The output is the
+ * same as pt_render's. */
+int pt_render_static(PtRenderer *r, const PtPushConstants *pc, void *rgba8_dev, void *f32_dev, void *hip_stream);
+
 /* Progressive accumulation (no counterpart in the reference, which draws one
  * sample per pixel at the pixel corner and never calls its random(), reference
  * shaders/raytrace.comp:117-119, 692-700).  Draws sub-pixel samples

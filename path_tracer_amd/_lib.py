@@ -31,6 +31,7 @@ SYMBOLS = [
     ("pt_assemble_bands", _I, [_VP, _VP, _VP, _I, _I, _I, _I]),
     ("pt_render_counted", _I, [_VP, _VP, _VP]),
     ("pt_render_samples", _I, [_VP, _VP, _I, _I, _I]),
+    ("pt_render_static", _I, [_VP, _VP, _VP, _VP, _VP]),
     ("pt_set_slot", _I, [_VP, _I, _VP, _VP, _VP]),
     ("pt_last_slot", _I, [_VP]),
     ("pt_device_rgba8", _VP, [_VP]),

@@ -223,6 +223,9 @@ constexpr int kStaticMaxTiles = 1 << 18; // 8x8-pixel tiles: frames up to 16.7 M
 constexpr size_t kStaticOrderOffset = 8192; // the counters block (kScratchBytes <= 8192) comes first
 constexpr size_t kStaticScratchBytes = kStaticOrderOffset + (size_t)3 * kStaticMaxTiles * sizeof(int);
 static_assert(kScratchBytes <= kStaticOrderOffset, "counter block outgrew its place in the static scratch");
+static __device__ __align__(256) unsigned char g_staticScratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+void *g_staticScratchPtr[kMaxDevices] = {}; // device address of g_staticScratch on device d (0: not fetched yet)
 
 // Where a frame goes when the caller fixes everything (pt_render_static); nullptr: a frame slot of the renderer.
 struct FrameTarget {
@@ -464,6 +467,16 @@ int pt_create(int width, int height, int device, PtRenderer **out) {
   std::snprintf(r->deviceName, sizeof r->deviceName, "%s (%s)", prop.name, prop.gcnArchName);
   int rc = ensure_slots(r, r->framesInFlight);
   if (rc != PT_OK) { pt_destroy(r); return rc; }
+  if (device < kMaxDevices && !g_staticScratchPtr[device]) {
+    // once per device, with that device current: the address of this GPU's copy of the static scratch
+    void *sp = nullptr;
+    e = hipGetSymbolAddress(&sp, HIP_SYMBOL(g_staticScratch));
+    if (e != hipSuccess || !sp) {
+      pt_destroy(r);
+      return fail(PT_ERR_HIP, std::string("hipGetSymbolAddress(static scratch): ") + hipGetErrorString(e));
+    }
+    g_staticScratchPtr[device] = sp;
+  }
   for (hipEvent_t *ev : {&r->evBegin, &r->evEnd}) {
     e = hipEventCreate(ev);
     if (e != hipSuccess) {
@@ -808,6 +821,21 @@ int pt_reset_voxels(PtRenderer *r) {
 }
 
 int pt_render(PtRenderer *r, const PtPushConstants *pc) { return launch_frame(r, pc, 0); }
+
+int pt_render_static(PtRenderer *r, const PtPushConstants *pc, void *rgba8_dev, void *f32_dev, void *hip_stream) {
+  if (!r || !pc || !rgba8_dev) return fail(PT_ERR_INVALID, "pt_render_static: renderer, push constants and the rgba8 frame are required");
+  if (r->device >= kMaxDevices || !g_staticScratchPtr[r->device])
+    return fail(PT_ERR_STATE, "pt_render_static: no static scratch on this device");
+  if (r->accumulate) return fail(PT_ERR_STATE, "pt_render_static: not inside pt_render_samples");
+  char *const base = (char *)g_staticScratchPtr[r->device];
+  FrameTarget t;
+  t.stream = hip_stream ? (hipStream_t)hip_stream : r->ownStream[0];
+  t.rgba8 = rgba8_dev;
+  t.f32 = f32_dev;
+  t.scratch = base;
+  t.tileOrder = (int *)(base + kStaticOrderOffset);
+  return launch_frame(r, pc, 0, &t);
+}
 
 int pt_render_samples(PtRenderer *r, const PtPushConstants *pc, int first_sample, int num_samples, int keep) {
   if (!r || !pc) return fail(PT_ERR_INVALID, "pt_render_samples: null argument");

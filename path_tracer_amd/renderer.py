@@ -143,6 +143,13 @@ class HipRenderer:
         pc = self._pc(pushConstants)
         _lib.check(self._lib.pt_render_samples(self._h, pc.ctypes.data, first_sample, num_samples, 1 if keep else 0))
 
+    def renderStatic(self, pushConstants, rgba8_ptr: int, f32_ptr: Optional[int] = None,
+                     stream_ptr: Optional[int] = None) -> None:
+        """pt_render_static: the frame into the caller's device buffers on the caller's stream, allocating
+        nothing (the frame's scratch is a static device array shared by every renderer on the GPU)."""
+        pc = self._pc(pushConstants)
+        _lib.check(self._lib.pt_render_static(self._h, pc.ctypes.data, rgba8_ptr, f32_ptr, stream_ptr))
+
     def setRowBands(self, band_rows: int, band_index: int, band_count: int) -> None:
         _lib.check(self._lib.pt_set_row_bands(self._h, band_rows, band_index, band_count))
 

@@ -31,6 +31,7 @@ int main() {
   if (rc == PT_OK) {
     PtPushConstants pc{};
     EXPECT(pt_render(r, &pc) == PT_ERR_STATE); // no scene yet
+    EXPECT(pt_render_static(r, &pc, nullptr, nullptr, nullptr) == PT_ERR_INVALID);
     PtGPUSphere s{};
     s.materialIndex = -1; // what SceneManager leaves on an object without a material
     EXPECT(pt_update_scene(r, &s, 1, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0) == PT_ERR_INVALID);
@@ -46,6 +47,7 @@ int main() {
   float ms = 0;
   uint8_t byte = 0;
   EXPECT(pt_render(nullptr, &pc) == PT_ERR_INVALID);
+  EXPECT(pt_render_static(nullptr, &pc, &byte, nullptr, nullptr) == PT_ERR_INVALID);
   EXPECT(pt_render_samples(nullptr, &pc, 0, 1, 0) == PT_ERR_INVALID);
   EXPECT(pt_render_counted(nullptr, &pc, counters) == PT_ERR_INVALID);
   EXPECT(pt_update_scene(nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0) == PT_ERR_INVALID);
