@@ -132,6 +132,10 @@ enum {
   PT_CNT_CYC_POOLED,      /* device only: wave-cycles from joining the pooled end-of-frame mode to exit */
   PT_CNT_POOLED_PASSES,   /* device only: passes made in pooled mode, summed over workgroups   */
   PT_CNT_POOLED_RAYS,     /* device only: rays traced through the pooled list                  */
+  PT_CNT_CYC_TICKET,      /* device only: wave-cycles waiting for tile tickets (part of CYC_REFILL) */
+  PT_CNT_TICKETS,         /* device only: tile tickets drawn                                   */
+  PT_CNT_CYC_TAIL,        /* device only: wave-cycles from a wave's finding the tickets drained to its exit */
+  PT_CNT_CYC_ALIVE,       /* device only: wave-cycles from start to exit, summed over the waves */
   PT_CNT_COUNT
 };
 

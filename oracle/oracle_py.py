@@ -14,7 +14,6 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
-N_COUNTERS = 21
 
 
 class _PtoScene(C.Structure):
@@ -116,7 +115,7 @@ def render(scene, max_bounces: Optional[int] = None, rows: Optional[Tuple[int, i
     r0, r1 = (0, H) if rows is None else rows
     rgba = np.zeros((H, W, 4), dtype=np.uint8)
     f32 = np.zeros((H, W, 4), dtype=np.float32) if want_f32 else None
-    cnt = np.zeros(N_COUNTERS, dtype=np.uint64)
+    cnt = np.zeros(int(lib().pto_counter_count()), dtype=np.uint64)  # as many as the C side writes
     if nthreads <= 0:
         nthreads = min(os.cpu_count() or 1, 16)
     opt = _PtoOptions(volume_filter, first_sample, num_samples)

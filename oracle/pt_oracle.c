@@ -720,6 +720,8 @@ static void *worker(void *arg) {
   return NULL;
 }
 
+int pto_counter_count(void) { return PT_CNT_COUNT; }
+
 int pto_render(const PtoScene *scene, const PtPushConstants *pc, int width,
                int height, int max_bounces, int row_begin, int row_end,
                float *out_f32, uint8_t *out_rgba8, uint64_t *counters,

@@ -44,6 +44,9 @@ int pto_render(const PtoScene *scene, const PtPushConstants *pc, int width,
                float *out_f32, uint8_t *out_rgba8, uint64_t *counters,
                int nthreads);
 
+/* Number of uint64 slots pto_render writes into `counters` (PT_CNT_COUNT of the build). */
+int pto_counter_count(void);
+
 /* Extensions without a counterpart in the reference (all zero = the reference). */
 typedef struct PtoOptions {
   int volume_filter; /* 0 nearest neighbour (raytrace.comp:485-517), 1 trilinear */

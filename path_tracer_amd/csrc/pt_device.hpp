@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   };
 #define PT_IMG(i) (LDS_OBJECTS ? s_obj[(i)] : ld_image(i))
 #define PT_ELL(j, k) PT_IMG(P.offEll + 4 * (j) + (k))
-#define PT_ELLP(p, k) ld_image(P.offEllPair + 7 * (p) + (k)) /* wave-uniform: scalar loads, like the sphere pairs */
+#define PT_ELLP(p, k) ld_image(P.offEllPair + 8 * (p) + (k)) /* wave-uniform: scalar loads, like the sphere pairs */
 #define PT_MAT(m, k) PT_IMG(P.offMat + 5 * (m) + (k))
 #define PT_LIGHT(i) PT_IMG(P.offLight + (i))
 #define PT_EMS(e, k) PT_IMG(P.offEmS + 3 * (e) + (k))
@@ -179,8 +179,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned int cExact = 0;              // rays this lane sent to the exact routine
   unsigned long long tPooled = 0, nPooled = 0, nPooledRays = 0;
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
+  unsigned long long cycTicket = 0, nTickets = 0, tExhausted = 0, tStart = 0;
 #define PT_PHASE(ACC) if (PHASES) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
-  if (PHASES) tPhase = __builtin_amdgcn_s_memtime();
+  if (PHASES) tStart = tPhase = __builtin_amdgcn_s_memtime();
 
   for (;;) {
     // ------------------------------------------------------------------
@@ -202,6 +203,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         // drained, then from the next group that still has tickets (peeked with a
         // plain load first, so drained groups cost no atomics).
         unsigned int t = 0xFFFFFFFFu;
+        unsigned long long tTicket = 0;
+        if (PHASES) { tTicket = __builtin_amdgcn_s_memtime(); nTickets++; }
         while (groupsTried < kTicketGroups) {
           const int g = (homeGroup + groupsTried) & (kTicketGroups - 1);
           const unsigned int owned = ((unsigned int)P.numTiles + (unsigned int)(kTicketGroups - 1 - g)) / kTicketGroups;
@@ -219,6 +222,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         }
         if (t >= (unsigned int)P.numTiles) {
           exhausted = true;
+          if (PHASES) tExhausted = __builtin_amdgcn_s_memtime();
         } else {
           if (P.tileOrder) {
             const int at = t < nClass2 ? 2 * P.numTiles + (int)t
@@ -229,6 +233,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           nextTx = (int)(t % (unsigned int)P.tilesX); // once per tile, wave-uniform
           nextTy = (int)(t / (unsigned int)P.tilesX);
         }
+        if (PHASES) cycTicket += __builtin_amdgcn_s_memtime() - tTicket;
       }
       const int rank = lanes_below(idleMask);
       int p = -1; // pixel within its tile
@@ -772,19 +777,31 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const P3 RO = splat3(rO), RD = splat3(rD);
         const f2 DD = mk2(dLen2q, dLen2q);
         for (int p = 0; 2 * p < Ne; ++p) {
-          const float4 g0 = PT_ELLP(p, 0), g1 = PT_ELLP(p, 1), g2 = PT_ELLP(p, 2), g3 = PT_ELLP(p, 3);
-          const float4 g4 = PT_ELLP(p, 4), g5 = PT_ELLP(p, 5), g6 = PT_ELLP(p, 6);
+          // Stage 1, the bounding sphere: V = (x.d)^2 - |d|^2 (|x|^2 c1 - c2) >= 0 is necessary for a root
+          // (c1, c2 from the host, see pt_update_scene); 12 packed instructions.
+          const float4 g0 = PT_ELLP(p, 0), g1 = PT_ELLP(p, 1), g2 = PT_ELLP(p, 2);
           const P3 x = sub3p(RO, mkp3(mk2(g0.x, g0.y), mk2(g0.z, g0.w), mk2(g1.x, g1.y)));
-          const P3 m0 = mkp3(mk2(g1.z, g1.w), mk2(g2.x, g2.y), mk2(g2.z, g2.w));
-          const P3 m1 = mkp3(mk2(g3.x, g3.y), mk2(g3.z, g3.w), mk2(g4.x, g4.y));
-          const P3 m2 = mkp3(mk2(g4.z, g4.w), mk2(g5.x, g5.y), mk2(g5.z, g5.w));
+          const f2 xd = dot3p(x, RD);
+          const f2 xx = dot3p(x, x);
+          const f2 inner = fma2(xx, mk2(g1.z, g1.w), mk2(g2.x, g2.y));
+          const f2 V = fma2(xd, xd, -(DD * inner));
+          const unsigned long long nearMask = ballot64(__builtin_fmaxf(V.x, V.y) >= 0.0f) & qMask;
+          if (nearMask == 0ull) continue;
+          // Stage 2, the quadratic through the matrix, for the pairs some ray of the wave comes near.
+          const float4 g3 = PT_ELLP(p, 3), g4 = PT_ELLP(p, 4), g5 = PT_ELLP(p, 5), g6 = PT_ELLP(p, 6), g7 = PT_ELLP(p, 7);
+          const P3 m0 = mkp3(mk2(g2.z, g2.w), mk2(g3.x, g3.y), mk2(g3.z, g3.w));
+          const P3 m1 = mkp3(mk2(g4.x, g4.y), mk2(g4.z, g4.w), mk2(g5.x, g5.y));
+          const P3 m2 = mkp3(mk2(g5.z, g5.w), mk2(g6.x, g6.y), mk2(g6.z, g6.w));
           const P3 y = mkp3(dot3p(m0, x), dot3p(m1, x), dot3p(m2, x));
           const P3 z = mkp3(dot3p(m0, RD), dot3p(m1, RD), dot3p(m2, RD));
           const f2 a = dot3p(z, z);
           const f2 hb = dot3p(y, z);
           const f2 c = fma2(y.z, y.z, fma2(y.y, y.y, fma2(y.x, y.x, mk2(-1.0f, -1.0f))));
           const f2 disc = fma2(hb, hb, -(a * c));
-          const f2 val = fma2(mk2(g6.x, g6.y) * DD, dot3p(x, x), fma2(mk2(g6.z, g6.w), DD, disc));
+          f2 val = fma2(mk2(g7.x, g7.y) * DD, xx, fma2(mk2(g7.z, g7.w), DD, disc));
+          // both tests are necessary conditions: a candidate passes both
+          if (!(V.x >= 0.0f)) val.x = -1.0f;
+          if (!(V.y >= 0.0f)) val.y = -1.0f;
           if ((ballot64(__builtin_fmaxf(val.x, val.y) >= -1.0e-30f) & qMask) != 0ull) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1383,6 +1400,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     atomicAdd(&P.counters[15], cycEll);
     atomicAdd(&P.counters[16], cycShade);
     atomicAdd(&P.counters[17], cycExact);
+    const unsigned long long tEnd = __builtin_amdgcn_s_memtime();
+    atomicAdd(&P.counters[21], cycTicket);
+    atomicAdd(&P.counters[22], nTickets);
+    if (exhausted) atomicAdd(&P.counters[23], tEnd - tExhausted);
+    atomicAdd(&P.counters[24], tEnd - tStart);
   }
   if (COUNT) {
     // wave reduction, then one atomic per counter per wave

@@ -44,10 +44,11 @@ struct FrameParams {
   //                w = radius, or with sphereFilter the filter constant k (see below)
   //   [offRadius)  one float per sphere: radius (read when a candidate's roots are evaluated)
   //   [offEll)     4 per ellipsoid: (c,qw) (1/radii,maxRadius) (-q.xyz,0) (-2q.xyz,0)
-  //   [offEllPair) 7 per pair of ellipsoids, every field as (first, second) of the pair:
-  //                (cx,cy) (cz,m00) (m01,m02) (m10,m11) (m12,m20) (m21,m22) (k1,k2): centre, the matrix
-  //                M = diag(1/radii) R(conjugate q) and the margin constants of the candidate loop; an odd
-  //                count is padded with a copy of the last ellipsoid
+  //   [offEllPair) 8 per pair of ellipsoids, every field as (first, second) of the pair:
+  //                (cx,cy) (cz,c1) (-c2,m00) (m01,m02) (m10,m11) (m12,m20) (m21,m22) (k1,k2): centre, the constants
+  //                of the bounding-sphere test, the matrix M = diag(1/radii) R(conjugate q) and the margin
+  //                constants of the matrix test (the two stages of the candidate loop); an odd count is padded
+  //                with a copy of the last ellipsoid
   //   [offMat)     5 per material, as GPUMaterial
   //   [offLight)   1 per light: (pos, intensity)
   //   [offEmS)     3 per emissive sphere, ascending sphere index:

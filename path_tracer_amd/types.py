@@ -99,6 +99,10 @@ COUNTER_NAMES = (
     "cyc_pooled",       # wave-cycles between joining the pooled end-of-frame mode and exit
     "pooled_passes",    # passes in pooled mode, summed over workgroups
     "pooled_rays",      # rays traced through the pooled list
+    "cyc_ticket",       # wave-cycles waiting for tile tickets (part of cyc_refill)
+    "tickets",          # tile tickets drawn
+    "cyc_tail",         # wave-cycles from a wave's finding the tickets drained to its exit
+    "cyc_alive",        # wave-cycles from start to exit, summed over the waves
 )
 N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 

@@ -11,6 +11,14 @@ rounded once), and adds a margin that covers the rounding of both evaluations:
     k1 = (124 g + 98) u mu^4, k2 = (31 g + 29) u mu^2, u = 2^-24, mu >= |M|_2,
     g = max(1/radii) (1 + 2 |q||qw| + 2 |q|^2) / mu   (the size of the shader's intermediates against |M|)
 
+Before the matrix test the loop runs a cheaper one on the bounding sphere: with sigma the smallest singular
+value of M, Rb = 1/sigma, x = o - c:
+
+    V = (x.d)^2 - |d|^2 (|x|^2 c1 - c2) >= 0,  c1 = 1 - Rb^4 k1 - 24 u (rounded down),
+                                               c2 = Rb^2 (1 + Rb^2 k2) (1 + 8 u) + 1e-30 (rounded up)
+
+which must also hold wherever the shader's discriminant is >= 0.
+
 Here both sides are evaluated with the kernel's operation order on random and grazing rays against
 random ellipsoids (anisotropy up to 8, unit and non-unit quaternions, scenes far from the origin):
 wherever hitEllipsoid's float32 discriminant is >= 0 the filter must pass.  float32 fused multiply-add
@@ -84,6 +92,37 @@ def host_constants(radii, quat):
     return M.astype(f32), k1, k2
 
 
+def sphere_constants(radii, quat):
+    """c1 and -c2 of the bounding-sphere stage, as the host computes them."""
+    M32, k1, k2 = host_constants(radii, quat)
+    # the host takes sigma from the double-precision M, before rounding it
+    q = [-quat[i].astype(np.float64) for i in range(3)]
+    qw = quat[3].astype(np.float64)
+    inv = [(f32(1.0) / radii[i]).astype(f32).astype(np.float64) for i in range(3)]
+    n = len(qw)
+    K = np.zeros((n, 3, 3))
+    K[:, 0, 1], K[:, 0, 2] = -q[2], q[1]
+    K[:, 1, 0], K[:, 1, 2] = q[2], -q[0]
+    K[:, 2, 0], K[:, 2, 1] = -q[1], q[0]
+    M = np.stack(inv, axis=1)[:, :, None] * (np.eye(3)[None] + 2.0 * qw[:, None, None] * K + 2.0 * (K @ K))
+    lmin = np.linalg.eigvalsh(np.transpose(M, (0, 2, 1)) @ M)[:, 0] * (1.0 - 1e-9)
+    rb2 = 1.0 / lmin
+    b1 = rb2 * rb2 * k1.astype(np.float64)
+    b2 = rb2 * (1.0 + rb2 * k2.astype(np.float64))
+    c1 = np.nextafter((1.0 - b1 - 24.0 * U).astype(f32), f32(-np.inf))
+    c2 = np.nextafter((b2 * (1.0 + 8.0 * U) + 1.0e-30).astype(f32), f32(np.inf))
+    return c1, (-c2).astype(f32)
+
+
+def sphere_value(o, d, ctr, c1, nc2):
+    x = [(o[i] - ctr[i]).astype(f32) for i in range(3)]
+    xd = dot3(x, d)
+    xx = dot3(x, x)
+    inner = fma(xx, c1, nc2)
+    dd = dot3(d, d)
+    return fma(xd, xd, -mul(dd, inner))
+
+
 def filter_value(o, d, ctr, M, k1, k2):
     x = [(o[i] - ctr[i]).astype(f32) for i in range(3)]
     y = [fma(M[:, i, 2], x[2], fma(M[:, i, 1], x[1], mul(M[:, i, 0], x[0]))) for i in range(3)]
@@ -139,6 +178,7 @@ def test_filter_never_rejects_an_ellipsoid_the_shader_would_evaluate():
         if scale < 1.0:
             radii = [(x * f32(scale)).astype(f32) for x in radii]
         M, k1, k2 = host_constants(radii, quat)
+        c1, nc2 = sphere_constants(radii, quat)
         for graze in (0.0, 0.9, 0.999, 0.99999, 1.0, 1.00001, 1.001, 1.05):
             o, d = _grazing_rays(rng, n, ctr, radii, quat, max(scale, 1.0) if scale >= 1.0 else scale, graze)
             disc = shader_discriminant(o, d, ctr, radii, quat)
@@ -147,6 +187,8 @@ def test_filter_never_rejects_an_ellipsoid_the_shader_would_evaluate():
             got = val >= f32(-1.0e-30)
             bad = need & ~got
             assert not bad.any(), (scale, ratio, qscale, graze, int(bad.sum()))
+            bad1 = need & ~(sphere_value(o, d, ctr, c1, nc2) >= 0)
+            assert not bad1.any(), ("bounding-sphere stage", scale, ratio, qscale, graze, int(bad1.sum()))
             checked += n; roots += int(need.sum()); passed += int(got.sum())
     assert roots > 0.2 * checked
     print(f"[ellipsoid filter] {checked} pairs, {roots} with a root, {passed} let through")
@@ -169,6 +211,10 @@ def test_filter_is_selective_for_ordinary_ellipsoids():
     disc = shader_discriminant(o, d, ctr, radii, quat)
     got = filter_value(o, d, ctr, M, k1, k2) >= f32(-1.0e-30)
     assert not ((disc >= 0) & ~got).any()
+    c1, nc2 = sphere_constants(radii, quat)
+    near = sphere_value(o, d, ctr, c1, nc2) >= 0
+    assert not ((disc >= 0) & ~near).any()
+    print(f"[ellipsoid filter] bounding-sphere stage lets through {int(near.sum())} of {n}")
     extra = int(got.sum()) - int((disc >= 0).sum())
     print(f"[ellipsoid filter] roots {int((disc >= 0).sum())}, extra candidates {extra}")
     assert extra <= 0.25 * (disc >= 0).sum()
