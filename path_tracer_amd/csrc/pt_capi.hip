@@ -159,6 +159,7 @@ struct PtRenderer {
 namespace {
 
 // dScratch: class counts (3 x 4 B) at +16, counters (PT_CNT_COUNT x 8 B) at +64, tile-ticket counters at +512
+static_assert(64 + PT_CNT_COUNT * sizeof(uint64_t) <= 512, "the work counters must end before the ticket counters");
 constexpr size_t kScratchBytes = 512 + (size_t)ptdev::kTicketGroups * ptdev::kTicketStride * sizeof(unsigned int);
 
 int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {

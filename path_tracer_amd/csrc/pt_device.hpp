@@ -180,7 +180,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned long long tPooled = 0, nPooled = 0, nPooledRays = 0;
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
   unsigned long long cycTicket = 0, nTickets = 0, tExhausted = 0, tStart = 0;
-#define PT_PHASE(ACC) if (PHASES) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
+  // MODE 2 always stamps a wave's start, its finding the tickets drained and its exit (three stamps per wave: the
+  // timeline of the production code); the per-phase and per-ticket stamps, which cost a scalar-memory round trip
+  // each and slow short passes down noticeably, only with tune bit 26.
+  const bool phaseStamps = PHASES && (P.tune & (1 << 26)) != 0;
+#define PT_PHASE(ACC) if (PHASES && phaseStamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
   if (PHASES) tStart = tPhase = __builtin_amdgcn_s_memtime();
 
   for (;;) {
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         // plain load first, so drained groups cost no atomics).
         unsigned int t = 0xFFFFFFFFu;
         unsigned long long tTicket = 0;
-        if (PHASES) { tTicket = __builtin_amdgcn_s_memtime(); nTickets++; }
+        if (PHASES && phaseStamps) { tTicket = __builtin_amdgcn_s_memtime(); nTickets++; }
         while (groupsTried < kTicketGroups) {
           const int g = (homeGroup + groupsTried) & (kTicketGroups - 1);
           const unsigned int owned = ((unsigned int)P.numTiles + (unsigned int)(kTicketGroups - 1 - g)) / kTicketGroups;
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           nextTx = (int)(t % (unsigned int)P.tilesX); // once per tile, wave-uniform
           nextTy = (int)(t / (unsigned int)P.tilesX);
         }
-        if (PHASES) cycTicket += __builtin_amdgcn_s_memtime() - tTicket;
+        if (PHASES && phaseStamps) cycTicket += __builtin_amdgcn_s_memtime() - tTicket;
       }
       const int rank = lanes_below(idleMask);
       int p = -1; // pixel within its tile
@@ -1403,8 +1407,14 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     const unsigned long long tEnd = __builtin_amdgcn_s_memtime();
     atomicAdd(&P.counters[21], cycTicket);
     atomicAdd(&P.counters[22], nTickets);
-    if (exhausted) atomicAdd(&P.counters[23], tEnd - tExhausted);
+    if (exhausted) {
+      atomicAdd(&P.counters[23], tEnd - tExhausted);
+      atomicMax(&P.counters[25], (1ull << 62) - (tExhausted - tStart));
+      atomicMax(&P.counters[26], tExhausted - tStart);
+    }
     atomicAdd(&P.counters[24], tEnd - tStart);
+    const unsigned long long bin = (tEnd - tStart) >> 15;
+    atomicAdd(&P.counters[27 + (bin < 28ull ? bin : 28ull)], 1ull);
   }
   if (COUNT) {
     // wave reduction, then one atomic per counter per wave
