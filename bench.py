@@ -10,7 +10,10 @@ spheres/ellipsoids, depth 8): value = Mrays/s over all N GPUs, a ray being one
 query of the whole object list (primary, bounce, light-shadow and
 emissive-occlusion rays).  With N > 1 the frame is split into interleaved
 16-row bands, one set per rank, and gathered to rank 0 over RCCL inside the
-timed region (strong scaling: the total work is fixed).
+timed region (strong scaling: the total work is fixed).  The gather is the
+library's own (pt_gather_bands: grouped ncclSend / ncclRecv behind the C-ABI);
+torch.distributed only carries the rendezvous, the barriers and the reduction
+of the timings (gloo, on the CPU).
 
 The same JSON line carries
   roofline      algorithmic FLOP (17 per sphere test, 91 per ellipsoid test,
@@ -71,10 +74,12 @@ def build_scene(name: str, scale: float = 1.0):
 class Runner:
     """One renderer on this rank's GPU, optionally band-split with a gather to rank 0.
 
-    backend "nccl": the compact frame is rendered straight into a torch CUDA
-    tensor on torch's stream, gathered over RCCL and de-interleaved by a device
-    kernel.  backend "gloo" (rehearsal on a box with fewer GPUs than ranks): the
-    compact frame is read back and gathered through host memory.
+    backend "rccl" (default): pt_gather_bands — the library sends / receives the compact frames over
+    RCCL on the frame's own stream and de-interleaves on rank 0; no torch tensor is involved.
+    backend "nccl": the compact frame is rendered straight into a torch CUDA tensor on a torch
+    stream, gathered with torch.distributed (RCCL) and de-interleaved by the library's kernel.
+    backend "gloo" (rehearsal on a box with fewer GPUs than ranks): the compact frame is read back
+    and gathered through host memory.
     """
 
     def __init__(self, scene, rank: int, world: int, device: int, torch_mod=None, dist=None, backend="nccl",
@@ -92,8 +97,15 @@ class Runner:
         self.r.setScene(scene)
         self.pc = scene.push_constants()
         self.bgs, self.frames, self.tstreams = [], [], []
+        self.comm = None
         self.split = (world > 1) if split is None else split
-        if self.split:
+        if self.split and backend == "rccl":
+            uid = [HipRenderer.commUniqueId() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self.comm = self.r.commCreate(uid[0], rank, world, device)
+            self.r.setRowBands(BAND_ROWS, rank, world)
+        elif self.split:
             t = torch_mod
             self.r.setRowBands(BAND_ROWS, rank, world)
             dev = f"cuda:{device}" if backend == "nccl" else "cpu"
@@ -121,7 +133,7 @@ class Runner:
         if not self.split:
             return values
         t = self.torch
-        dev = self.bg.local.device
+        dev = self.bg.local.device if self.bg is not None else "cpu"
         x = t.tensor(values, dtype=t.float64, device=dev)
         self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
         return x.cpu().numpy()
@@ -136,7 +148,9 @@ class Runner:
         else:
             self.r.render(self.pc)
         if self.split:
-            if self.backend == "nccl":
+            if self.backend == "rccl":
+                self.r.gatherBands(self.comm, 4)  # on the stream of the frame just drawn
+            elif self.backend == "nccl":
                 slot = self.last = self.r.lastSlot()
                 bg = self.bgs[slot]
                 with self.torch.cuda.stream(self.tstreams[slot]):
@@ -186,22 +200,34 @@ class Runner:
             return self.r.readbackRGBA8()
         if self.rank != 0:
             return None
+        if self.backend == "rccl":
+            return self.r.readbackAssembled(4)
         return self.frames[self.last].cpu().numpy() if self.backend == "nccl" else self.host_frame
 
     def close(self):
+        self.r.present()
+        if self.comm is not None:
+            self.r.commDestroy(self.comm)
+            self.comm = None
         self.r.shutdown()
 
 
 def measured_traffic(workload: str):
-    """HBM-side bytes per launch of the timed kernel for this workload, from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE need a pass each and cannot be collected from inside this process).  The workloads
-    are deterministic, so the per-launch figure of the profiled build carries over; None when no profile exists."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    """Memory-side bytes per launch of the timed kernel for this workload: FETCH_SIZE and WRITE_SIZE of the rocprofv3
+    PMC passes that tools/round_profile.sh ran on THIS build (they need a pass each and cannot be read from inside the
+    process); profiles/traffic.json records the hash of the sources it was measured on, and a file from any other
+    build is ignored (None).  FETCH_SIZE is doubled, as on gfx950 it tallies 128-byte requests at 64 bytes."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
+        import __graft_entry__ as g
+
         with open(path) as f:
-            t = json.load(f).get(workload)
-        return None if t is None else float(t["fetch_bytes"] + t["write_bytes"])
-    except (OSError, ValueError, KeyError):
+            doc = json.load(f)
+        if doc.get("source_hash") != g.source_hash():
+            return None
+        t = doc.get(workload)
+        return None if t is None else float(2.0 * t["fetch_bytes"] + t["write_bytes"])
+    except (OSError, ValueError, KeyError, ImportError):
         return None
 
 
@@ -258,8 +284,10 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (testing only; 1.0 = the named config)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4/C5 side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for --gpus > 1 (gloo = host-memory rehearsal)")
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="gather for --gpus > 1: rccl = the library's pt_gather_bands (RCCL behind the C-ABI; torch.distributed "
+                         "only for rendezvous and barriers, on gloo), nccl = torch.distributed.gather on CUDA tensors, "
+                         "gloo = host-memory rehearsal")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the final frame against a single-GPU render")
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=range(1, 9),
@@ -294,7 +322,7 @@ def main():
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
+        else:  # rccl: the library talks to RCCL itself; the process group is the control plane only
             dist_mod.init_process_group("gloo")
         torch_mod, dist = torch, dist_mod
     if args.gpus != world and rank == 0 and world > 1:
@@ -317,8 +345,15 @@ def main():
         run.set_frames_in_flight(fif)
     else:
         dt1, ev1_ms = dt, ev_ms
+    # Steady state: with frames in flight the K timed frames hold one frame's start-up and tail, so ms_per_step falls
+    # as K grows; the rate between frame 20 and frame 120 of one run is what a long sequence sees per frame.
+    steady = None
+    if fif >= 2 and args.scale == 1.0:
+        d_a, _ = run.timed(20, 2)
+        d_b, _ = run.timed(120, 2)
+        steady = max(d_b - d_a, 0.0) / 100.0
     check = None
-    if args.check and (world > 1 or args.force_split):
+    if (args.check or world > 1) and (world > 1 or args.force_split):
         frame = run.final_frame()
         if rank == 0:
             solo = Runner(scene, 0, 1, local_rank, frames_in_flight=1)
@@ -355,6 +390,17 @@ def main():
                                      measured_traffic(args.workload) if args.scale == 1.0 else None) if n_gpus == 1 else None,
         }
         result["frames_in_flight"] = fif
+        if n_gpus == 1:
+            # the headline mode itself: the algorithmic FLOP of the K timed frames over the HIP-event time of the region
+            hl = roofline_for(cnt, ev_ms / args.steps)
+            hl.pop("traffic", None)
+            hl["note"] = (f"headline mode, {fif} frames in flight: FLOP of the {args.steps} timed frames / HIP-event time of the "
+                          "whole region (kernels of consecutive frames overlap, so this is not one launch's duration)")
+            result["roofline_frames_in_flight"] = hl
+        if steady is not None:
+            unit_count = float(cnt[6]) if args.workload == "c4" else float(cnt[0])
+            result["steady_state"] = {"ms_per_step": round(steady * 1e3, 4), "value": round(unit_count / steady / 1e6, 2),
+                                      "unit": unit, "note": "(time of 120 frames - time of 20 frames) / 100, same mode as the headline"}
         if fif >= 2:
             unit_count = float(cnt[6]) if args.workload == "c4" else rays
             result["one_frame_at_a_time"] = {
@@ -387,6 +433,16 @@ def main():
                             "rays_per_frame": float(c[0]), "roofline": roofline_for(c, e / steps, measured_traffic(name))}
             if name == "c4":
                 extras[name]["Msamples_per_s"] = round(c[6] / (d / steps) / 1e6, 2)
+                # the trilinear quality mode (no counterpart in the reference): 8 voxel bytes per sample
+                rr = Runner(sc, 0, 1, local_rank, frames_in_flight=1)
+                rr.r.setOption(5, 1)  # PT_OPT_VOLUME_FILTER
+                ct = rr.counters()
+                dt_, et_ = rr.timed(steps, 1)
+                rr.close()
+                extras[name]["trilinear"] = {
+                    "ms_per_frame": round(dt_ / steps * 1e3, 4), "Msamples_per_s": round(ct[6] / (dt_ / steps) / 1e6, 2),
+                    "requested_GBs": round(ct[6] * 8 / (et_ / steps * 1e-3) / 1e9, 1),
+                    "note": "PT_OPT_VOLUME_FILTER = 1: 8 one-byte voxel fetches per sample, bricked volume"}
         if args.workload != "c5":
             # 64 samples per pixel at 4K (C2's objects + the volume): one launch per sample, running mean on the device
             sc = build_scene("c5")

@@ -129,6 +129,7 @@ public:
   }
 
   void shutdown() {
+    leaveGather();
     if (handle_) pt_destroy(handle_);
     handle_ = nullptr;
   }
@@ -190,6 +191,41 @@ public:
 
   const std::unordered_map<std::string, int> &getShaderPathToIndexMap() const { return shaderPathToIndex_; }
 
+  // ---- multi-GPU: one process (or thread) per GPU, interleaved row bands, gather to rank 0 over RCCL ----
+  // Rank 0 makes the id and hands it to the other ranks (file, socket, MPI ...); then every rank calls
+  // joinGather (collective).  After that render() draws this rank's bands only, gather() sends them to rank 0
+  // (rank 0: receives, de-interleaves) on the frame's stream, and rank 0 reads the whole frame with
+  // readbackAssembledRGBA8().  The reference is single-GPU (reference src/main_vulkan.cpp:105-389).
+  static bool gatherUniqueId(std::vector<uint8_t> &id) {
+    id.assign(PT_COMM_ID_BYTES, 0);
+    return pt_comm_unique_id(id.data(), id.size()) == PT_OK;
+  }
+  bool joinGather(const std::vector<uint8_t> &id, int rank, int world, int device = 0, int bandRows = 16) {
+    if (!handle_) return false;
+    leaveGather();
+    if (pt_comm_create(id.data(), id.size(), rank, world, device, &comm_) != PT_OK ||
+        pt_set_row_bands(handle_, bandRows, rank, world) != PT_OK) {
+      std::cerr << "HipRenderer::joinGather: " << pt_last_error() << std::endl;
+      leaveGather();
+      return false;
+    }
+    rank_ = rank;
+    return true;
+  }
+  void leaveGather() {
+    if (comm_) pt_comm_destroy(comm_);
+    comm_ = nullptr;
+  }
+  void gather() {
+    if (handle_ && comm_ && pt_gather_bands(handle_, comm_, 4, nullptr) != PT_OK)
+      std::cerr << "HipRenderer::gather: " << pt_last_error() << std::endl;
+  }
+  bool readbackAssembledRGBA8(std::vector<uint8_t> &out) { // rank 0
+    if (!handle_ || rank_ != 0) return false;
+    out.resize((size_t)width_ * height_ * 4);
+    return pt_readback_assembled(handle_, out.data(), out.size()) == PT_OK;
+  }
+
   // ---- beyond the reference interface ----
   int width() const { return width_; }
   int height() const { return height_; }
@@ -220,6 +256,8 @@ public:
 
 private:
   PtRenderer *handle_ = nullptr;
+  PtComm *comm_ = nullptr;
+  int rank_ = 0;
   int width_ = 0, height_ = 0;
   bool honourMaxDepth_ = false, sceneOk_ = true;
   std::vector<GPUSphere> spheres_;

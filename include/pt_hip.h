@@ -143,6 +143,30 @@ int pt_local_rows(PtRenderer *r);
 int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
                       int band_rows, int band_count, int stride_rows);
 
+/* The gather itself over RCCL, without any framework in between (one process per
+ * GPU, scene replicated, interleaved row bands, one exchange at the end of the frame).  RCCL is opened at run
+ * time (librccl.so.1); programs that never call these do not need it.
+ *   pt_comm_unique_id   rank 0 makes the PT_COMM_ID_BYTES that identify the communicator and hands them to the
+ *                       other ranks by whatever means the program has (a file, MPI, torch.distributed, a socket);
+ *   pt_comm_create      every rank, collectively (ncclCommInitRank on `device`);
+ *   pt_gather_bands     after pt_render, on every rank, in the same order on all ranks: ranks 1 .. world-1 send
+ *                       their compact band-major frame (elem_bytes 4: the rgba8 frame, 16: the float frame) to
+ *                       rank 0, each over its own xGMI link; rank 0 posts the matching receives as one group
+ *                       (ncclGroupStart / ncclRecv x (world-1) / ncclGroupEnd), copies its own bands beside them
+ *                       and de-interleaves everything into `dst_dev` (height x width elements; NULL: a frame
+ *                       the renderer owns, see pt_device_assembled / pt_readback_assembled).  Everything is
+ *                       enqueued on the stream of the frame just drawn, so frames in flight overlap their
+ *                       gathers; pt_present waits for all of it.  pt_set_row_bands(rows, rank, world) must have
+ *                       been called with the communicator's rank and world.  world = 1 is allowed (a copy). */
+#define PT_COMM_ID_BYTES 128
+typedef struct PtComm PtComm;
+int pt_comm_unique_id(void *id_out, size_t id_bytes);
+int pt_comm_create(const void *id, size_t id_bytes, int rank, int world, int device, PtComm **out);
+void pt_comm_destroy(PtComm *c);
+int pt_gather_bands(PtRenderer *r, PtComm *c, int elem_bytes, void *dst_dev);
+void *pt_device_assembled(PtRenderer *r);
+int pt_readback_assembled(PtRenderer *r, void *dst, size_t dst_bytes);
+
 /* Run the instrumented kernel for one frame (same image, untimed) and return
  * the PT_CNT_* work counters. */
 int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters);

@@ -29,6 +29,12 @@ SYMBOLS = [
     ("pt_set_row_bands", _I, [_VP, _I, _I, _I]),
     ("pt_local_rows", _I, [_VP]),
     ("pt_assemble_bands", _I, [_VP, _VP, _VP, _I, _I, _I, _I]),
+    ("pt_comm_unique_id", _I, [_VP, _SZ]),
+    ("pt_comm_create", _I, [_VP, _SZ, _I, _I, _I, C.POINTER(_VP)]),
+    ("pt_comm_destroy", None, [_VP]),
+    ("pt_gather_bands", _I, [_VP, _VP, _I, _VP]),
+    ("pt_device_assembled", _VP, [_VP]),
+    ("pt_readback_assembled", _I, [_VP, _VP, _SZ]),
     ("pt_render_counted", _I, [_VP, _VP, _VP]),
     ("pt_render_samples", _I, [_VP, _VP, _I, _I, _I]),
     ("pt_render_static", _I, [_VP, _VP, _VP, _VP, _VP]),

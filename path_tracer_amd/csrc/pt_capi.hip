@@ -8,6 +8,9 @@
 #include "pt_device.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types only: the library is opened at run time (dlopen), single-GPU users do not need it
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -152,8 +155,19 @@ struct PtRenderer {
   int bandRows = 0, bandIndex = 0, bandCount = 1;
   int localRows = 0;
 
+  // band gather (pt_gather_bands): per slot, rank 0's staging for every rank's compact frame; one assembled frame
+  DevBuf dGathered[kMaxSlots];
+  DevBuf dAssembled[kMaxSlots];
+  int assembledElem[kMaxSlots] = {};
+
   // last launch
   int lastBlocks = 0, lastThreads = 0, lastLds = 0;
+};
+
+// RCCL, bound at run time.
+struct PtComm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
 };
 
 namespace {
@@ -441,9 +455,149 @@ int upload(DevBuf &buf, const std::vector<T> &host, hipStream_t stream) {
   return PT_OK;
 }
 
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+// Opens librccl.so.1 (the copy a host program such as PyTorch has already loaded, if any: same SONAME) and binds
+// the few entry points the gather needs.
+int load_rccl() {
+  if (g_rccl.handle) return PT_OK;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(PT_ERR_STATE, std::string("RCCL is not available: ") + dlerror());
+  RcclApi a;
+  a.handle = h;
+#define PT_BIND(field, name)                                                     \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                 \
+  if (!a.field) return fail(PT_ERR_STATE, std::string("RCCL lacks ") + name);
+  PT_BIND(GetUniqueId, "ncclGetUniqueId")
+  PT_BIND(CommInitRank, "ncclCommInitRank")
+  PT_BIND(CommDestroy, "ncclCommDestroy")
+  PT_BIND(GroupStart, "ncclGroupStart")
+  PT_BIND(GroupEnd, "ncclGroupEnd")
+  PT_BIND(Send, "ncclSend")
+  PT_BIND(Recv, "ncclRecv")
+  PT_BIND(GetErrorString, "ncclGetErrorString")
+#undef PT_BIND
+  g_rccl = a;
+  return PT_OK;
+}
+
+#define PT_NCCL_CHECK(expr)                                                                            \
+  do {                                                                                                 \
+    ncclResult_t n_ = (expr);                                                                          \
+    if (n_ != ncclSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(n_)); \
+  } while (0)
+
 } // namespace
 
 extern "C" {
+
+int pt_comm_unique_id(void *id_out, size_t id_bytes) {
+  if (!id_out || id_bytes < sizeof(ncclUniqueId)) return fail(PT_ERR_INVALID, "pt_comm_unique_id: need a buffer of PT_COMM_ID_BYTES");
+  int rc = load_rccl();
+  if (rc != PT_OK) return rc;
+  ncclUniqueId id;
+  PT_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof id);
+  return PT_OK;
+}
+
+int pt_comm_create(const void *id, size_t id_bytes, int rank, int world, int device, PtComm **out) {
+  if (!out) return fail(PT_ERR_INVALID, "pt_comm_create: out is null");
+  *out = nullptr;
+  if (!id || id_bytes < sizeof(ncclUniqueId)) return fail(PT_ERR_INVALID, "pt_comm_create: need the PT_COMM_ID_BYTES of pt_comm_unique_id");
+  if (world < 1 || rank < 0 || rank >= world) return fail(PT_ERR_INVALID, "pt_comm_create: need 0 <= rank < world");
+  int rc = load_rccl();
+  if (rc != PT_OK) return rc;
+  PT_HIP_CHECK(hipSetDevice(device));
+  PtComm *c = new (std::nothrow) PtComm();
+  if (!c) return fail(PT_ERR_NOMEM, "pt_comm_create: out of host memory");
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof uid);
+  ncclResult_t n = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+  if (n != ncclSuccess) {
+    delete c;
+    return fail(PT_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(n));
+  }
+  *out = c;
+  return PT_OK;
+}
+
+void pt_comm_destroy(PtComm *c) {
+  if (!c) return;
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+}
+
+int pt_gather_bands(PtRenderer *r, PtComm *c, int elem_bytes, void *dst_dev) {
+  if (!r || !c) return fail(PT_ERR_INVALID, "pt_gather_bands: null argument");
+  if (elem_bytes != 4 && elem_bytes != 16) return fail(PT_ERR_INVALID, "pt_gather_bands: elem_bytes is 4 (rgba8) or 16 (float4)");
+  if (c->device != r->device) return fail(PT_ERR_INVALID, "pt_gather_bands: communicator and renderer are on different devices");
+  if (r->bandCount != c->world || r->bandIndex != c->rank)
+    return fail(PT_ERR_STATE, "pt_gather_bands: pt_set_row_bands(rows, rank, world) must match the communicator");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  const int slot = r->lastSlot;
+  const hipStream_t stream = r->stream[slot];
+  const void *local = elem_bytes == 4 ? slot_rgba8(r, slot) : slot_f32(r, slot);
+  if (!local) return fail(PT_ERR_STATE, "pt_gather_bands: no frame of that kind (float output is off)");
+  const int bandRows = r->bandCount > 1 ? r->bandRows : std::max(r->height, 1);
+  const int strideRows = compute_local_rows(r->height, bandRows, 0, r->bandCount); // rank 0 has the most rows
+  const size_t rowBytes = (size_t)r->width * (size_t)elem_bytes;
+  const size_t partBytes = (size_t)strideRows * rowBytes;
+  if (c->rank != 0) {
+    // every peer has its own xGMI link to rank 0; the compact frame goes in one message
+    PT_NCCL_CHECK(g_rccl.Send(local, (size_t)r->localRows * rowBytes, ncclUint8, 0, c->comm, stream));
+    return PT_OK;
+  }
+  PT_HIP_CHECK(r->dGathered[slot].reserve(partBytes * (size_t)c->world));
+  char *const gathered = (char *)r->dGathered[slot].p;
+  void *dst = dst_dev;
+  if (!dst) {
+    PT_HIP_CHECK(r->dAssembled[slot].reserve((size_t)r->height * rowBytes));
+    dst = r->dAssembled[slot].p;
+  }
+  r->assembledElem[slot] = elem_bytes;
+  PT_HIP_CHECK(hipMemcpyAsync(gathered, local, (size_t)r->localRows * rowBytes, hipMemcpyDeviceToDevice, stream));
+  if (c->world > 1) {
+    PT_NCCL_CHECK(g_rccl.GroupStart());
+    for (int p = 1; p < c->world; ++p) {
+      const size_t rows = (size_t)compute_local_rows(r->height, bandRows, p, c->world);
+      ncclResult_t n = g_rccl.Recv(gathered + (size_t)p * partBytes, rows * rowBytes, ncclUint8, p, c->comm, stream);
+      if (n != ncclSuccess) {
+        (void)g_rccl.GroupEnd();
+        return fail(PT_ERR_HIP, std::string("ncclRecv: ") + g_rccl.GetErrorString(n));
+      }
+    }
+    PT_NCCL_CHECK(g_rccl.GroupEnd());
+  }
+  return pt_assemble_bands(r, gathered, dst, elem_bytes, bandRows, c->world, strideRows);
+}
+
+void *pt_device_assembled(PtRenderer *r) { return r ? r->dAssembled[r->lastSlot].p : nullptr; }
+
+int pt_readback_assembled(PtRenderer *r, void *dst, size_t dst_bytes) {
+  if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_assembled: null argument");
+  const int slot = r->lastSlot;
+  if (!r->dAssembled[slot].p || !r->assembledElem[slot]) return fail(PT_ERR_STATE, "pt_readback_assembled: no assembled frame (pt_gather_bands on rank 0 with dst_dev = NULL makes one)");
+  const size_t bytes = (size_t)r->width * r->height * (size_t)r->assembledElem[slot];
+  if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_assembled: destination too small");
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
+  PT_HIP_CHECK(hipMemcpy(dst, r->dAssembled[slot].p, bytes, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
 
 int pt_create(int width, int height, int device, PtRenderer **out) {
   if (!out) return fail(PT_ERR_INVALID, "pt_create: out is null");
@@ -500,6 +654,7 @@ void pt_destroy(PtRenderer *r) {
   for (DevBuf *b : bufs) b->release();
   for (int k = 0; k < PtRenderer::kMaxSlots; ++k) {
     r->dRgba8[k].release(); r->dF32[k].release(); r->dScratch[k].release(); r->dTileOrder[k].release();
+    r->dGathered[k].release(); r->dAssembled[k].release();
     if (r->evCross[k]) (void)hipEventDestroy(r->evCross[k]);
     if (r->ownStream[k]) (void)hipStreamDestroy(r->ownStream[k]);
   }

@@ -158,6 +158,34 @@ class HipRenderer:
         _lib.check(self._lib.pt_assemble_bands(self._h, src_ptr, dst_ptr, elem_bytes, band_rows, band_count,
                                                stride_rows))
 
+    # ---- the gather over RCCL behind the C-ABI (no torch involved) ----
+    @staticmethod
+    def commUniqueId() -> bytes:
+        """Rank 0: the bytes that identify a new communicator; hand them to every other rank."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        _lib.check(lib.pt_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def commCreate(self, unique_id: bytes, rank: int, world: int, device: int = 0):
+        """Collective over all ranks: joins the communicator and switches this renderer to rank's row bands."""
+        comm = C.c_void_p()
+        _lib.check(self._lib.pt_comm_create(unique_id, len(unique_id), rank, world, device, C.byref(comm)))
+        return comm
+
+    def commDestroy(self, comm) -> None:
+        if comm:
+            self._lib.pt_comm_destroy(comm)
+
+    def gatherBands(self, comm, elem_bytes: int = 4, dst_ptr: Optional[int] = None) -> None:
+        _lib.check(self._lib.pt_gather_bands(self._h, comm, elem_bytes, dst_ptr))
+
+    def readbackAssembled(self, elem_bytes: int = 4) -> np.ndarray:
+        """Rank 0: the frame pt_gather_bands assembled into the renderer's own buffer."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8 if elem_bytes == 4 else np.float32)
+        _lib.check(self._lib.pt_readback_assembled(self._h, out.ctypes.data, out.nbytes))
+        return out
+
     def setOutput(self, rgba8_ptr: Optional[int], f32_ptr: Optional[int] = None) -> None:
         _lib.check(self._lib.pt_set_output(self._h, rgba8_ptr, f32_ptr))
 

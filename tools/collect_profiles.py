@@ -77,6 +77,13 @@ def main():
         if fdb and wdb:
             traffic[wl] = {"fetch_bytes": kernel_counter(fdb[0], "FETCH_SIZE") * 1024.0,
                            "write_bytes": kernel_counter(wdb[0], "WRITE_SIZE") * 1024.0}
+    # the build these passes ran on: bench.py only quotes a traffic.json measured on the build it is running
+    try:
+        with open(os.path.join(src, "source_hash.txt")) as f:
+            traffic["source_hash"] = f.read().strip()
+    except OSError:
+        traffic["source_hash"] = None
+    traffic["unit"] = "bytes per launch of pt_render_kernel<0,...>; FETCH_SIZE and WRITE_SIZE as rocprofv3 reports them (KiB x 1024), uncorrected"
     for name in (f"{rnd}_traffic.json", "traffic.json"):  # traffic.json = the latest, read by bench.py
         with open(os.path.join(out, name), "w") as f:
             json.dump(traffic, f, indent=1)

@@ -3,7 +3,7 @@
 #   1. the default bench line (bench.py --steps 10 --warmup 2)
 #   2. rocprofv3 --kernel-trace --stats of the same command with --frames-in-flight 1 (the mode the roofline object
 #      describes: kernels of consecutive frames do not overlap, a launch's duration is that of a kernel running alone)
-#   3. PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE — one pass each) for workloads c2, c3, c4
+#   3. PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE, L2 hit/miss/request counters — one pass each) for workloads c2, c3, c4
 set -u
 tag=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
@@ -21,5 +21,7 @@ for wl in c2 c3 c4; do
   timeout -s KILL 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU -d $out/pmc_valu_$wl -o p -- $B > $out/pmc_valu_$wl.log 2>&1 || { echo pmc valu $wl failed; exit 1; }
   timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch_$wl -o p -- $B > $out/pmc_fetch_$wl.log 2>&1 || { echo pmc fetch $wl failed; exit 1; }
   timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write_$wl -o p -- $B > $out/pmc_write_$wl.log 2>&1 || { echo pmc write $wl failed; exit 1; }
+  timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum -d $out/pmc_l2_$wl -o p -- $B > $out/pmc_l2_$wl.log 2>&1 || { echo pmc l2 $wl failed; exit 1; }
 done
+python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import __graft_entry__ as g; print(g.source_hash())" > $out/source_hash.txt
 echo profile done
