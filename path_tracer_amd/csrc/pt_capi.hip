@@ -310,6 +310,12 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
       P.extent[i] = v.v1[i] - v.v0[i];       // reference shaders/raytrace.comp:503
       P.rcpExtent[i] = (float)(1.0 / (double)P.extent[i]);
     }
+    P.exactExtent = 1;
+    for (int i = 0; i < 3; ++i) {
+      int e = 0;
+      const float m = std::frexp(P.extent[i], &e); // a power of two with a representable reciprocal: mantissa 1/2, exponent in range
+      if (!(m == 0.5f) || e < -100 || e > 100) P.exactExtent = 0;
+    }
     P.res[0] = v.resolution_x; P.res[1] = v.resolution_y; P.res[2] = v.resolution_z;
     P.volMaterial = v.materialIndex;
   }

@@ -1100,6 +1100,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               const float cellTolX = 1.5f * 0x1p-22f * (float)L.res[0], cellTolY = 1.5f * 0x1p-22f * (float)L.res[1],
                           cellTolZ = 1.5f * 0x1p-22f * (float)L.res[2];
               const uint8_t *__restrict__ vox = P.voxels;
+              const bool exactExtent = L.exactExtent != 0;
               const bool bricked = P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
               const int nbx = P.brickX, nby = P.brickY;
               if (L.volumeFilter == 1) {
@@ -1176,15 +1177,17 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                     const float ax = rel.x - lo.x, ay = rel.y - lo.y, az = rel.z - lo.z;
                     const float px = (ax * rcpEx) * rxf, py = (ay * rcpEy) * ryf, pz = (az * rcpEz) * rzf;
                     int ix = (int)px, iy = (int)py, iz = (int)pz;
-                    const bool sure = __builtin_fabsf(__builtin_amdgcn_fractf(px) - 0.5f) < 0.5f - cellTolX &&
-                                      __builtin_fabsf(__builtin_amdgcn_fractf(py) - 0.5f) < 0.5f - cellTolY &&
-                                      __builtin_fabsf(__builtin_amdgcn_fractf(pz) - 0.5f) < 0.5f - cellTolZ;
-                    if (!sure) { // also where a product is not a number
-                      ix = (int)((ax / ext.x) * rxf); iy = (int)((ay / ext.y) * ryf); iz = (int)((az / ext.z) * rzf);
+                    if (!exactExtent) { // where every extent is a power of two the product IS the shader's quotient
+                      const bool sure = __builtin_fabsf(__builtin_amdgcn_fractf(px) - 0.5f) < 0.5f - cellTolX &&
+                                        __builtin_fabsf(__builtin_amdgcn_fractf(py) - 0.5f) < 0.5f - cellTolY &&
+                                        __builtin_fabsf(__builtin_amdgcn_fractf(pz) - 0.5f) < 0.5f - cellTolZ;
+                      if (!sure) { // also where a product is not a number
+                        ix = (int)((ax / ext.x) * rxf); iy = (int)((ay / ext.y) * ryf); iz = (int)((az / ext.z) * rzf);
+                      }
                     }
-                    ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix);
-                    iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
-                    iz = iz < 0 ? 0 : (iz > rz - 1 ? rz - 1 : iz);
+                    ix = __builtin_elementwise_min(__builtin_elementwise_max(ix, 0), rx - 1);
+                    iy = __builtin_elementwise_min(__builtin_elementwise_max(iy, 0), ry - 1);
+                    iz = __builtin_elementwise_min(__builtin_elementwise_max(iz, 0), rz - 1);
                     index[u] = bricked ? ((((iz >> 3) * nby + (iy >> 3)) * nbx + (ix >> 3)) << 9) +
                                              (((iz & 7) << 6) | ((iy & 7) << 3) | (ix & 7))
                                        : ix + iy * rx + iz * rx * ry;
