@@ -194,7 +194,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // Idle lanes take the next pixels of the pool in lane order; when the pool
     // runs out part-way, the rest continue in the next tile (fetched first).
     const unsigned long long idleMask = ballot64(state == ST_IDLE);
-    if (idleMask != 0ull && !(exhausted && poolNext == poolEnd)) {
+    // The refill has a fixed cost per pass, whatever the number of lanes it fills; where a pass over the objects is
+    // cheap next to it (few objects), it waits until P.refillMin lanes are idle (or nothing else is left to do).
+    if (idleMask != 0ull && !(exhausted && poolNext == poolEnd) &&
+        ((int)__popcll(idleMask) >= P.refillMin || idleMask == ~0ull)) {
       const int nIdle = __popcll(idleMask);
       const int avail = poolEnd - poolNext;
       int nextBase = -1; // first pixel of the following tile, if one is needed and left

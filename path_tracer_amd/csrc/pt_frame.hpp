@@ -89,6 +89,7 @@ struct FrameParams {
   float rcpExtent[3]; // 1 / extent[i], rounded once (from a double on the host): the march's fast voxel index
   int exactExtent;    // 1: every extent[i] is a power of two, so x * rcpExtent[i] is exactly the quotient x / extent[i]
   int sparseLanes;  // at most this many live rays in a wave: trace them one by one (exact routine)
+  int refillMin;    // idle lanes that make the refill of a wave worth its fixed cost (1: any idle lane is refilled at once)
   int tune;         // tuning switches of pt_set_option(100, ...), 0 in production; the kernel reads bit 0: no wave priorities
 };
 
