@@ -171,6 +171,11 @@ int pt_readback_assembled(PtRenderer *r, void *dst, size_t dst_bytes);
  * the PT_CNT_* work counters. */
 int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters);
 
+/* Profiling aid: draws one frame with the kernel that stamps the clock three times per wave and
+ * returns, for wave i of the launch, out[4i .. 4i+3] = the 100 MHz clock (s_memrealtime) at its start, when it found the tile tickets
+ * drained, at its exit, and the number of passes it made.  *num_waves = waves of the launch. */
+int pt_wave_timeline(PtRenderer *r, const PtPushConstants *pc, uint64_t *out, size_t capacity_waves, int *num_waves);
+
 /* pt_render without any allocation.  No counterpart in the reference; it is for
  * callers that cannot call hipMalloc where they render: code under HIP graph
  * capture, tight serving loops, harnesses that forbid allocation.  Draws the

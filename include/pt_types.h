@@ -110,7 +110,6 @@ _Static_assert(sizeof(PtPushConstants) == 144, "PushConstants is 144 bytes");
 /* Per-frame work counters, filled by the oracle and by the instrumented
  * (untimed) device kernel.  A "ray" is one closest-hit / any-hit query
  * against the whole object list (reference shaders/raytrace.comp:212-241). */
-#define PT_END_HIST_BINS 29
 enum {
   PT_CNT_RAYS = 0,        /* all traceRay queries                         */
   PT_CNT_PATH_RAYS,       /* primary + bounce rays                        */
@@ -137,10 +136,7 @@ enum {
   PT_CNT_TICKETS,         /* device only: tile tickets drawn                                   */
   PT_CNT_CYC_TAIL,        /* device only: wave-cycles from a wave's finding the tickets drained to its exit */
   PT_CNT_CYC_ALIVE,       /* device only: wave-cycles from start to exit, summed over the waves */
-  PT_CNT_DRY_FIRST,       /* device only: cycles from a wave's start to its finding the tickets drained, minimum over waves (stored as 2^62 - value) */
-  PT_CNT_DRY_LAST,        /* device only: the same, maximum over waves */
-  PT_CNT_END_HIST,        /* device only: first of PT_END_HIST_BINS bins: waves by lifetime in units of 2^15 cycles (last bin: longer) */
-  PT_CNT_COUNT = PT_CNT_END_HIST + 29
+  PT_CNT_COUNT
 };
 
 #ifdef __cplusplus

@@ -123,6 +123,8 @@ struct PtRenderer {
   bool volumeBricks = true;                  // PT_OPT_VOLUME_BRICKS
   int volumeFilter = 0;                      // PT_OPT_VOLUME_FILTER
   DevBuf dAccum;                             // float4 sum per pixel (pt_render_samples)
+  DevBuf dWaveLog;                           // pt_wave_timeline: 4 words per wave
+  bool wantWaveLog = false;
   int accumCount = 0;                        // samples in dAccum
   int sampleIndex = 0;                       // sample drawn by the next launch
   bool accumulate = false;
@@ -341,6 +343,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   P.outF32 = (float4 *)(fixed ? fixed->f32 : slot_f32(r, slot));
   P.tileCounter = (unsigned int *)(scratch + 512);
   P.counters = (unsigned long long *)(scratch + 64);
+  P.waveLog = (mode == 2 && r->wantWaveLog) ? (unsigned long long *)r->dWaveLog.p : nullptr;
 
   if (P.numTiles <= 0) return PT_OK;
   // The ordering pass pays off when pixels differ a lot in the number of rays
@@ -663,7 +666,7 @@ void pt_destroy(PtRenderer *r) {
   (void)hipSetDevice(r->device);
   for (int k = 0; k < r->numSlots; ++k)
     if (r->stream[k]) (void)hipStreamSynchronize(r->stream[k]);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dBricks, &r->dAccum};
+  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dBricks, &r->dAccum, &r->dWaveLog};
   for (DevBuf *b : bufs) b->release();
   for (int k = 0; k < PtRenderer::kMaxSlots; ++k) {
     r->dRgba8[k].release(); r->dF32[k].release(); r->dScratch[k].release(); r->dTileOrder[k].release();
@@ -1088,6 +1091,26 @@ int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counte
   uint64_t cyc[PT_CNT_COUNT];
   PT_HIP_CHECK(hipMemcpy(cyc, (char *)r->dScratch[0].p + 64, sizeof cyc, hipMemcpyDeviceToHost));
   for (int i = PT_CNT_CYC_REFILL; i < PT_CNT_COUNT; ++i) counters[i] = cyc[i];
+  return PT_OK;
+}
+
+int pt_wave_timeline(PtRenderer *r, const PtPushConstants *pc, uint64_t *out, size_t capacity_waves, int *num_waves) {
+  if (!r || !pc || !out || !num_waves) return fail(PT_ERR_INVALID, "pt_wave_timeline: null argument");
+  const size_t maxWaves = (size_t)r->computeUnits * 16 * 2; // more than any launch of the frame kernel has
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
+  PT_HIP_CHECK(r->dWaveLog.reserve(maxWaves * 32));
+  PT_HIP_CHECK(hipMemset(r->dWaveLog.p, 0, maxWaves * 32));
+  r->wantWaveLog = true;
+  rc = launch_frame(r, pc, 2);
+  r->wantWaveLog = false;
+  if (rc != PT_OK) return rc;
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream[0]));
+  const size_t waves = (size_t)r->lastBlocks * (size_t)(r->lastThreads / 64);
+  *num_waves = (int)waves;
+  const size_t n = std::min(waves, capacity_waves);
+  PT_HIP_CHECK(hipMemcpy(out, r->dWaveLog.p, n * 32, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 

@@ -180,14 +180,18 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned long long tPooled = 0, nPooled = 0, nPooledRays = 0;
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
   unsigned long long cycTicket = 0, nTickets = 0, tExhausted = 0, tStart = 0;
+  unsigned long long rtStart = 0, rtDry = 0; // s_memrealtime stamps (one clock for the whole chip, unlike s_memtime)
+  unsigned int nPasses = 0;
   // MODE 2 always stamps a wave's start, its finding the tickets drained and its exit (three stamps per wave: the
   // timeline of the production code); the per-phase and per-ticket stamps, which cost a scalar-memory round trip
   // each and slow short passes down noticeably, only with tune bit 26.
   const bool phaseStamps = PHASES && (P.tune & (1 << 26)) != 0;
 #define PT_PHASE(ACC) if (PHASES && phaseStamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ACC += now_ - tPhase; tPhase = now_; }
   if (PHASES) tStart = tPhase = __builtin_amdgcn_s_memtime();
+  if (PHASES && P.waveLog) rtStart = __builtin_amdgcn_s_memrealtime();
 
   for (;;) {
+    if (PHASES) nPasses++;
     // ------------------------------------------------------------------
     // 1. refill idle lanes from the wave's tile pool
     // ------------------------------------------------------------------
@@ -230,6 +234,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         if (t >= (unsigned int)P.numTiles) {
           exhausted = true;
           if (PHASES) tExhausted = __builtin_amdgcn_s_memtime();
+          if (PHASES && P.waveLog) rtDry = __builtin_amdgcn_s_memrealtime();
         } else {
           if (P.tileOrder) {
             const int at = t < nClass2 ? 2 * P.numTiles + (int)t
@@ -1401,7 +1406,15 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   }
 #undef PT_PHASE
 
-  if (PHASES && lane == 0) {
+  if (PHASES && lane == 0 && P.waveLog) {
+    // Timeline run: one record per wave and no atomics (thousands of same-address atomics at the end of the
+    // kernel would stretch the very tail the timeline is there to show).
+    unsigned long long *rec = P.waveLog + 4ull * ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (unsigned long long)waveInBlock);
+    rec[0] = rtStart;
+    rec[1] = exhausted ? rtDry : 0ull;
+    rec[2] = __builtin_amdgcn_s_memrealtime();
+    rec[3] = nPasses;
+  } else if (PHASES && lane == 0) {
     if (coop) atomicAdd(&P.counters[18], __builtin_amdgcn_s_memtime() - tPooled);
     atomicAdd(&P.counters[19], nPooled);
     atomicAdd(&P.counters[20], nPooledRays);
@@ -1413,14 +1426,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     const unsigned long long tEnd = __builtin_amdgcn_s_memtime();
     atomicAdd(&P.counters[21], cycTicket);
     atomicAdd(&P.counters[22], nTickets);
-    if (exhausted) {
-      atomicAdd(&P.counters[23], tEnd - tExhausted);
-      atomicMax(&P.counters[25], (1ull << 62) - (tExhausted - tStart));
-      atomicMax(&P.counters[26], tExhausted - tStart);
-    }
+    if (exhausted) atomicAdd(&P.counters[23], tEnd - tExhausted);
     atomicAdd(&P.counters[24], tEnd - tStart);
-    const unsigned long long bin = (tEnd - tStart) >> 15;
-    atomicAdd(&P.counters[27 + (bin < 28ull ? bin : 28ull)], 1ull);
   }
   if (COUNT) {
     // wave reduction, then one atomic per counter per wave

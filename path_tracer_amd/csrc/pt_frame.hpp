@@ -66,6 +66,7 @@ struct FrameParams {
   float4 *outF32;           // may be null
   unsigned int *tileCounter;    // kTicketGroups counters, kTicketStride apart
   unsigned long long *counters; // PT_CNT_COUNT slots, instrumented kernel only
+  unsigned long long *waveLog;  // or null; phase-instrumented kernel: 4 words per wave (start, tickets drained, exit stamps; passes)
   // Optional drawing order (null: tiles are drawn in index order).  tileOrder holds
   // three lists of numTiles entries each, one per cost class; classCount[c] is the
   // length of list c.  Tickets run through class 2, then 1, then 0.

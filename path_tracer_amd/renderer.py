@@ -137,6 +137,14 @@ class HipRenderer:
         _lib.check(self._lib.pt_render_counted(self._h, pc.ctypes.data, cnt.ctypes.data))
         return cnt
 
+    def waveTimeline(self, pushConstants) -> np.ndarray:
+        """[waves, 4] uint64: start / tickets-drained / exit clock stamps and pass count of every wave of one frame."""
+        pc = self._pc(pushConstants)
+        out = np.zeros((16384, 4), dtype=np.uint64)
+        n = C.c_int()
+        _lib.check(self._lib.pt_wave_timeline(self._h, pc.ctypes.data, out.ctypes.data, len(out), C.byref(n)))
+        return out[:n.value]
+
     def renderSamples(self, pushConstants, first_sample: int = 0, num_samples: int = 1, keep: bool = False) -> None:
         """Mean of sub-pixel samples first_sample .. first_sample + num_samples - 1 (sample 0 is the
         reference's pixel-corner sample); keep=True continues the previous call's sum."""

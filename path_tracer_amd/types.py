@@ -103,9 +103,7 @@ COUNTER_NAMES = (
     "tickets",          # tile tickets drawn
     "cyc_tail",         # wave-cycles from a wave's finding the tickets drained to its exit
     "cyc_alive",        # wave-cycles from start to exit, summed over the waves
-    "dry_first",        # cycles from start until the first wave found the tickets drained (stored as 2^62 - value)
-    "dry_last",         # ... until the last wave did
-) + tuple(f"end_hist_{i}" for i in range(29))  # waves by lifetime, bins of 2^15 cycles
+)
 N_ALGORITHM_COUNTERS = 10  # the slots the oracle fills too
 
 # Compiled-in surface shaders, keyed by the path string the reference's

@@ -188,3 +188,23 @@ def test_a_larger_resolution_later_keeps_the_uploaded_voxels(oracle):
         np.testing.assert_array_equal(cnt[:10], want[2][:10])
         np.testing.assert_array_equal(got.view(np.uint32), want[1].view(np.uint32))
         assert got[..., :3].max() > 0 and (got[..., :3] != got[0, 0, :3]).any()  # the volume is visible
+
+
+def test_wave_timeline_draws_the_same_frame_and_orders_its_stamps():
+    """pt_wave_timeline: one record per wave of the launch, start <= tickets drained <= exit on the chip-wide
+    clock, at least one pass each, and the frame it draws is the plain frame."""
+    sc = scenes.config2(480, 270, max_depth=6)
+    pc = sc.push_constants()
+    r = _renderer(sc)
+    plain = _frame(r, pc)[1]
+    t = r.waveTimeline(pc)
+    blocks, threads, _ = r.lastLaunch()
+    assert t.shape == (blocks * threads // 64, 4)
+    r.present()
+    np.testing.assert_array_equal(plain.view(np.uint32), r.readbackF32().view(np.uint32))
+    start, dry, end, passes = (t[:, i].astype(np.int64) for i in range(4))
+    assert (passes >= 1).all() and (end >= start).all()
+    found = dry != 0  # a wave that never needed another tile has no such stamp
+    assert found.any() and (dry[found] >= start[found]).all() and (end[found] >= dry[found]).all()
+    assert (end.max() - start.min()) < 100_000_000  # under a second of the 100 MHz clock
+    r.shutdown()

@@ -6,7 +6,7 @@ sc = {'c3':scenes.config3,'c2':scenes.config2,'c4':scenes.config4}[name]()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
 r.setOption(1,0); r.setOption(100,tune|(1<<26)); r.setScene(sc); pc = sc.push_constants()
 cnt = r.renderCounted(pc)  # with the per-phase stamps
-r.setOption(100,tune); light = r.renderCounted(pc)  # start / dry / exit stamps only: the production timeline
+
 tot=sum(int(cnt[i]) for i in range(13,18))
 print(name,'tune',tune,'phase share: refill %.3f spheres %.3f ellipsoids %.3f shade %.3f exact %.3f; cycles/pass/wave %.0f' % tuple([int(cnt[i])/tot for i in range(13,18)]+[tot/(cnt[0]/64)]))
 c=dict(zip(__import__('path_tracer_amd').types.COUNTER_NAMES,[int(x) for x in cnt]))
@@ -20,8 +20,3 @@ for _ in range(20): r.render(pc)
 r.present(); dt=(time.perf_counter()-t0)/20
 b,t,l=r.lastLaunch()
 print('ms/frame %.4f; waves %d; alive share of kernel time at 2.1 GHz: %.3f' % (dt*1e3, b*t//64, c['cyc_alive']/(b*t/64)/(dt*2.1e9)))
-c=dict(zip(__import__('path_tracer_amd').types.COUNTER_NAMES,[int(x) for x in light]))
-h=[c[f'end_hist_{i}'] for i in range(29)]
-tot=sum(h); acc=0
-print('alive wave-cycles without the phase stamps %.3e;' % c['cyc_alive'], 'tickets ran dry between %.0f and %.0f kcycles after start; waves by lifetime (bins of 32.8 kcycles, cumulative share):' % (((1<<62)-c['dry_first'])/1e3, c['dry_last']/1e3))
-print(' '.join('%d:%.2f' % (i, (acc:=acc+h[i])/tot) for i in range(29) if h[i]))
