@@ -365,6 +365,7 @@ def main():
     kernel_ms = ev1_ms / args.steps
     dev_name, cus = run.r.deviceInfo()
     launch = run.r.lastLaunch()
+    side_by_side = run.r.streamConcurrency() if fif >= 2 else 1  # what the device gives the slots' streams
     run.close()
 
     result = None
@@ -390,6 +391,7 @@ def main():
                                      measured_traffic(args.workload) if args.scale == 1.0 else None) if n_gpus == 1 else None,
         }
         result["frames_in_flight"] = fif
+        result["streams_side_by_side"] = side_by_side
         if n_gpus == 1:
             # the headline mode itself: the algorithmic FLOP of the K timed frames over the HIP-event time of the region
             hl = roofline_for(cnt, ev_ms / args.steps)

@@ -171,6 +171,15 @@ int pt_readback_assembled(PtRenderer *r, void *dst, size_t dst_bytes);
  * the PT_CNT_* work counters. */
 int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counters);
 
+/* How many of the PT_OPT_FRAMES_IN_FLIGHT slots' streams the device really runs side by side (streams share the
+ * process's hardware queues: GPU_MAX_HW_QUEUES, 4 by default, less what other libraries in the process took).
+ * The library measures it once per change of the slots (a device synchronisation and a few milliseconds, at the
+ * first frame after the change or at this call) and sizes the launches of frames in flight by it: a frame with few
+ * tiles per wave takes 1/n of the compute units so that the n frames run side by side with full waves instead of
+ * one after the other with emptying ones.  No counterpart in the reference (one queue, MAX_FRAMES_IN_FLIGHT = 2,
+ * reference include/VulkanRenderer.h:126). */
+int pt_stream_concurrency(PtRenderer *r, int *streams);
+
 /* Profiling aid: draws one frame with the kernel that stamps the clock three times per wave and
  * returns, for wave i of the launch, out[4i .. 4i+3] = the 100 MHz clock (s_memrealtime) at its start, when it found the tile tickets
  * drained, at its exit, and the number of passes it made.  *num_waves = waves of the launch. */

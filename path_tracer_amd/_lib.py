@@ -35,6 +35,7 @@ SYMBOLS = [
     ("pt_gather_bands", _I, [_VP, _VP, _I, _VP]),
     ("pt_device_assembled", _VP, [_VP]),
     ("pt_readback_assembled", _I, [_VP, _VP, _SZ]),
+    ("pt_stream_concurrency", _I, [_VP, C.POINTER(_I)]),
     ("pt_wave_timeline", _I, [_VP, _VP, _VP, _SZ, C.POINTER(_I)]),
     ("pt_render_counted", _I, [_VP, _VP, _VP]),
     ("pt_render_samples", _I, [_VP, _VP, _I, _I, _I]),

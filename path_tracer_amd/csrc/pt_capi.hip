@@ -111,6 +111,7 @@ struct PtRenderer {
   hipEvent_t evCross[kMaxSlots] = {};
   int numSlots = 0;                  // slots with a stream: 0 .. numSlots-1
   int framesInFlight = 2;            // PT_OPT_FRAMES_IN_FLIGHT
+  int concurrency = 0;               // streams of slots 0 .. framesInFlight-1 the device runs side by side (0: not measured yet)
   int lastSlot = 0;                  // slot of the most recent frame (what readback and pt_device_* show)
 
   // scene
@@ -224,6 +225,47 @@ bool pipelined(const PtRenderer *r) {
     if ((r->extRgba8[k] == nullptr) != (r->extRgba8[0] == nullptr)) return false;
   }
   return true;
+}
+
+// How many of the slots' streams run side by side?  Streams share hardware queues (GPU_MAX_HW_QUEUES, 4 unless
+// the environment says otherwise, and other users of the device in the process take their part), and two streams on
+// one queue run one after the other.  One 1 ms spin per stream, all released together: the time they take all
+// together tells.  Costs a device synchronisation and two to ten milliseconds, once per change of the slots.
+int measure_concurrency(PtRenderer *r) {
+  const int k = r->framesInFlight;
+  r->concurrency = 1;
+  if (k < 2) return PT_OK;
+  int rc = sync_all(r);
+  if (rc != PT_OK) return rc;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  PT_HIP_CHECK(hipEventCreate(&ev[0]));
+  hipError_t e = hipEventCreate(&ev[1]);
+  if (e != hipSuccess) { (void)hipEventDestroy(ev[0]); return fail(PT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+  const float spinMs = 1.0f;
+  auto run = [&]() -> hipError_t {
+    hipError_t h;
+    if ((h = hipEventRecord(ev[0], r->stream[0])) != hipSuccess) return h;
+    for (int s = 1; s < k; ++s) if ((h = hipStreamWaitEvent(r->stream[s], ev[0], 0)) != hipSuccess) return h;
+    for (int s = 0; s < k; ++s) hipLaunchKernelGGL(ptdev::pt_spin_kernel, dim3(1), dim3(64), 0, r->stream[s], (unsigned long long)(spinMs * 1e5f));
+    if ((h = hipGetLastError()) != hipSuccess) return h;
+    for (int s = 1; s < k; ++s) {
+      if ((h = hipEventRecord(r->evCross[s], r->stream[s])) != hipSuccess) return h;
+      if ((h = hipStreamWaitEvent(r->stream[0], r->evCross[s], 0)) != hipSuccess) return h;
+    }
+    if ((h = hipEventRecord(ev[1], r->stream[0])) != hipSuccess) return h;
+    return hipEventSynchronize(ev[1]);
+  };
+  e = run();          // the first launch on a stream includes its set-up
+  if (e == hipSuccess) e = run();
+  float ms = 0.0f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev[0], ev[1]);
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("measuring the streams' concurrency: ") + hipGetErrorString(e));
+  // k spins in ms: ms / spinMs of them came one after the other
+  const int serial = std::max(1, (int)(ms / spinMs + 0.7f));
+  r->concurrency = std::max(1, std::min(k, (k + serial - 1) / serial));
+  return PT_OK;
 }
 
 void *slot_rgba8(const PtRenderer *r, int slot) { return r->extRgba8[slot] ? r->extRgba8[slot] : r->dRgba8[slot].p; }
@@ -428,6 +470,27 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
   int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
+  // Frames in flight share the chip.  A frame with few tiles per wave (one rank's share of a split) is nearly all
+  // end-of-frame work when it takes every compute unit: its lanes empty out as paths end and nothing refills them.
+  // With k frames running side by side such a frame takes only a part of the resident workgroups, so that its waves draw
+  // several tiles each and stay full until the tickets run out, while the other frames fill the rest of the chip.
+  // Measured on one rank's 1/8 share (kernel ms per frame, whole launch -> this rule): 4096 spheres at 4K, 8 in
+  // flight 2.30 -> 2.15, 4 in flight 2.45 -> 2.38 (2 in flight: 2.71 -> 2.88, so the pooled kernel keeps the whole
+  // launch below 4); 64 objects at 1080p, 8 in flight 0.087 -> 0.079; volume only, 8 in flight 0.036 -> 0.021.
+  // Tune bits 27-29 = n > 0 force a launch of 1/2^(n-1) of the workgroups instead.
+  if (mode == 0 && pipelined(r) && !fixed) {
+    if (r->concurrency == 0) {
+      int rcM = measure_concurrency(r);
+      if (rcM != PT_OK) return rcM;
+    }
+    const long long full = (long long)r->computeUnits * blocksPerCu;
+    const int k = r->concurrency; // frames that really run side by side
+    const int part = P.coop ? (k >= 4 ? k : 1) : std::max(1, k / 2);
+    const long long perBlock = (long long)(P.coop ? 32 : 16) * (threads / 64); // more tiles per wave than this gain nothing
+    blocks = (int)std::min<long long>(blocks, std::max((full + part - 1) / part, (P.numTiles + perBlock - 1) / perBlock));
+  }
+  if ((r->tune >> 27) & 7) blocks = std::max(1, (r->computeUnits * blocksPerCu) >> (((r->tune >> 27) & 7) - 1));
+  blocks = (int)std::min<long long>(blocks, std::max<long long>(blocksNeeded, 1));
 
   PT_HIP_CHECK(hipMemsetAsync(scratch, 0, kScratchBytes, stream));
   if (P.tileOrder) {
@@ -1201,6 +1264,7 @@ int pt_set_slot(PtRenderer *r, int slot, void *hip_stream, void *rgba8_dev, void
   if (rc != PT_OK) return rc;
   if ((rc = ensure_slots(r, slot + 1)) != PT_OK) return rc;
   r->stream[slot] = hip_stream ? (hipStream_t)hip_stream : r->ownStream[slot];
+  r->concurrency = 0;
   r->extRgba8[slot] = rgba8_dev;
   r->extF32[slot] = f32_dev;
   return PT_OK;
@@ -1222,6 +1286,18 @@ int pt_set_stream(PtRenderer *r, void *hip_stream) {
   int rc = sync_all(r);
   if (rc != PT_OK) return rc;
   r->stream[0] = hip_stream ? (hipStream_t)hip_stream : r->ownStream[0];
+  r->concurrency = 0;
+  return PT_OK;
+}
+
+int pt_stream_concurrency(PtRenderer *r, int *streams) {
+  if (!r || !streams) return fail(PT_ERR_INVALID, "pt_stream_concurrency: null argument");
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  if (r->concurrency == 0 || r->framesInFlight < 2) {
+    int rc = measure_concurrency(r);
+    if (rc != PT_OK) return rc;
+  }
+  *streams = r->concurrency;
   return PT_OK;
 }
 
@@ -1265,6 +1341,7 @@ int pt_set_option(PtRenderer *r, int option, int value) {
       if (rcSlots != PT_OK) return rcSlots;
     }
     r->framesInFlight = value;
+    r->concurrency = 0;
     if (r->lastSlot >= value) r->lastSlot = 0;
     return PT_OK;
   case PT_OPT_VOLUME_FILTER:

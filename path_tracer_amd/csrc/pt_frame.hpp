@@ -239,6 +239,13 @@ __global__ void __launch_bounds__(256) pt_brick_volume_kernel(const uint8_t *__r
   }
 }
 
+// Occupies its stream for `ticks` of the 100 MHz chip-wide clock (the host uses it to find out how many of the
+// renderer's streams the device really runs side by side).  The clock advances by itself, so every wave leaves.
+__global__ void __launch_bounds__(64) pt_spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 template <typename T>
 __global__ void pt_assemble_bands_kernel(const T *__restrict__ src, T *__restrict__ dst, int width, int height,
                                          int bandRows, int bandCount, int strideRows) {

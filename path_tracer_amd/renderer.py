@@ -137,6 +137,12 @@ class HipRenderer:
         _lib.check(self._lib.pt_render_counted(self._h, pc.ctypes.data, cnt.ctypes.data))
         return cnt
 
+    def streamConcurrency(self) -> int:
+        """Slots' streams the device runs side by side (measured; see pt_stream_concurrency)."""
+        n = C.c_int()
+        _lib.check(self._lib.pt_stream_concurrency(self._h, C.byref(n)))
+        return n.value
+
     def waveTimeline(self, pushConstants) -> np.ndarray:
         """[waves, 4] uint64: start / tickets-drained / exit clock stamps and pass count of every wave of one frame."""
         pc = self._pc(pushConstants)
