@@ -208,3 +208,31 @@ def test_wave_timeline_draws_the_same_frame_and_orders_its_stamps():
     assert found.any() and (dry[found] >= start[found]).all() and (end[found] >= dry[found]).all()
     assert (end.max() - start.min()) < 100_000_000  # under a second of the 100 MHz clock
     r.shutdown()
+
+
+def test_launches_sized_by_the_streams_side_by_side_draw_the_same_frame():
+    """With frames in flight a frame with few tiles per wave takes a part of the compute units only (as many
+    parts as streams really run side by side, which the library measures); the frames stay bit-identical to
+    frames drawn one at a time, for the pooled kernel (>= 256 spheres) and the other."""
+    for sc in (scenes.config2(640, 360, max_depth=5), scenes.config3(640, 360, n_spheres=400, max_depth=4)):
+        pc = sc.push_constants()
+        solo = _renderer(sc, {T.OPT_FRAMES_IN_FLIGHT: 1})
+        want = _frame(solo, pc)[1].copy()
+        full_blocks = solo.lastLaunch()[0]
+        assert solo.streamConcurrency() == 1
+        solo.shutdown()
+        r = _renderer(sc, {T.OPT_FRAMES_IN_FLIGHT: 8})
+        n = r.streamConcurrency()
+        assert 1 <= n <= 8
+        for _ in range(9):
+            r.render(pc)
+        blocks = r.lastLaunch()[0]
+        assert blocks <= full_blocks
+        if n >= 4:
+            assert blocks < full_blocks  # the part of the chip one frame takes
+        r.present()
+        np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want.view(np.uint32))
+        for k in range(8):  # every slot holds the same frame
+            r.render(pc)
+            np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want.view(np.uint32))
+        r.shutdown()
