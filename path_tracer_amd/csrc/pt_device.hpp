@@ -1157,19 +1157,69 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                   stepCount++;
                 }
               }
+              // Index of the (clamped) cell (ix, iy, iz).  Bricked: ((bz * nby + by) * nbx + bx) * 512 + (iz & 7) * 64 +
+              // (iy & 7) * 8 + (ix & 7) with b = i >> 3, written as the linear part ix + 8 iy + 64 iz plus what each
+              // whole brick adds along its axis; the factors fit 24 bits (the host keeps the linear layout otherwise).
+              const int brickRowStep = (nbx << 9) - 64, bricksPerSliceLess1 = nbx * nby - 1;
+              auto cellIndex = [&](int ix, int iy, int iz) -> int {
+                if (!bricked) return ix + iy * rx + iz * rx * ry;
+                int id = ix + (iy << 3) + (iz << 6);
+                id += __mul24(ix >> 3, 504);
+                id += __mul24(iy >> 3, brickRowStep);
+                return id + (__mul24(iz >> 3, bricksPerSliceLess1) << 9);
+              };
+              // clamp(int(p), 0, res - 1) as int(clamp(p, 0, res - 1)): the same integer for every p (the conversion
+              // truncates towards zero and saturates; res - 1 is a float exactly)
+              const float topX = rxf - 1.0f, topY = ryf - 1.0f, topZ = rzf - 1.0f;
+              // Samples a lane takes at tSafeA <= t <= tSafeB are inside the box whatever the rounding of their
+              // position, so they skip sampleVolume's six comparisons: the position is linear in t, both ends of that
+              // stretch lie inside every slab by a margin of 1e-5 of the magnitudes that enter the position (its
+              // rounding error is below 3e-7 of them), hence so does everything between them.  The stretch leaves out
+              // the first and the last hundredth of the chord, where the entry and exit faces are closer than that.
+              float tSafeA = kMaxDistance, tSafeB = -kMaxDistance;
+              if (exactExtent && L.volumeFilter != 1) {
+                const float ta = tNear + 0.01f, tb = tFar - 0.01f;
+                const V3 pa = sub3(madd3(rO, ta, curD), vpos), pb = sub3(madd3(rO, tb, curD), vpos);
+                const float mx = 1e-5f * (__builtin_fabsf(rO.x) + __builtin_fabsf(vpos.x) + __builtin_fabsf(lo.x) + __builtin_fabsf(hi.x) + tFar * __builtin_fabsf(curD.x));
+                const float my = 1e-5f * (__builtin_fabsf(rO.y) + __builtin_fabsf(vpos.y) + __builtin_fabsf(lo.y) + __builtin_fabsf(hi.y) + tFar * __builtin_fabsf(curD.y));
+                const float mz = 1e-5f * (__builtin_fabsf(rO.z) + __builtin_fabsf(vpos.z) + __builtin_fabsf(lo.z) + __builtin_fabsf(hi.z) + tFar * __builtin_fabsf(curD.z));
+                const bool inside = glmin(pa.x, pb.x) >= lo.x + mx && glmax(pa.x, pb.x) <= hi.x - mx &&
+                                    glmin(pa.y, pb.y) >= lo.y + my && glmax(pa.y, pb.y) <= hi.y - my &&
+                                    glmin(pa.z, pb.z) >= lo.z + mz && glmax(pa.z, pb.z) <= hi.z - mz;
+                if (ta <= tb && inside) { tSafeA = ta; tSafeB = tb; }
+              }
+              const float scaleX = rcpEx * rxf, scaleY = rcpEy * ryf, scaleZ = rcpEz * rzf; // exact where the extents are powers of two
               // The march has no data-dependent exit, so four steps are taken per
               // trip: their voxel loads are in flight together and the accumulation
               // then runs in step order, exactly as one step per trip would.
               while (t < tFar && stepCount < 500) {
                 float ts[4];
-                int index[4];
-                int n = 1;
                 ts[0] = t;
 #pragma unroll
-                for (int u = 1; u < 4; ++u) {
-                  ts[u] = ts[u - 1] + 0.02f;
-                  if (n == u && ts[u] < tFar && stepCount + u < 500) n = u + 1;
+                for (int u = 1; u < 4; ++u) ts[u] = ts[u - 1] + 0.02f;
+                if (ballot64(!(ts[0] >= tSafeA && ts[3] <= tSafeB && stepCount <= 496)) == 0ull) {
+                  // every marching lane of the wave has four samples inside the box: no tests, no masks
+                  // (ts[3] <= tSafeB < tFar: all four are taken; (a * rcpE) * res = a * (rcpE * res), both scalings exact)
+                  unsigned int raw[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    const V3 rel = sub3(madd3(rO, ts[u], curD), vpos);
+                    const int ix = (int)__builtin_amdgcn_fmed3f((rel.x - lo.x) * scaleX, 0.0f, topX);
+                    const int iy = (int)__builtin_amdgcn_fmed3f((rel.y - lo.y) * scaleY, 0.0f, topY);
+                    const int iz = (int)__builtin_amdgcn_fmed3f((rel.z - lo.z) * scaleZ, 0.0f, topZ);
+                    raw[u] = (unsigned int)vox[cellIndex(ix, iy, iz)];
+                  }
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(1.0f - acc, s_div255[raw[u]] * absorptionCoeff, acc);
+                  t = ts[3] + 0.02f;
+                  stepCount += 4;
+                  continue;
                 }
+                int index[4];
+                int n = 1;
+#pragma unroll
+                for (int u = 1; u < 4; ++u)
+                  if (n == u && ts[u] < tFar && stepCount + u < 500) n = u + 1;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                   // sampleVolume (:485-517), nearest neighbour
@@ -1183,22 +1233,17 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                     // the quotient), so away from an integer by more than cellTol = 1.5 * 2^-22 * resolution it has the
                     // same integer part; the few samples closer than that take the division.
                     const float ax = rel.x - lo.x, ay = rel.y - lo.y, az = rel.z - lo.z;
-                    const float px = (ax * rcpEx) * rxf, py = (ay * rcpEy) * ryf, pz = (az * rcpEz) * rzf;
-                    int ix = (int)px, iy = (int)py, iz = (int)pz;
+                    float px = (ax * rcpEx) * rxf, py = (ay * rcpEy) * ryf, pz = (az * rcpEz) * rzf;
                     if (!exactExtent) { // where every extent is a power of two the product IS the shader's quotient
                       const bool sure = __builtin_fabsf(__builtin_amdgcn_fractf(px) - 0.5f) < 0.5f - cellTolX &&
                                         __builtin_fabsf(__builtin_amdgcn_fractf(py) - 0.5f) < 0.5f - cellTolY &&
                                         __builtin_fabsf(__builtin_amdgcn_fractf(pz) - 0.5f) < 0.5f - cellTolZ;
                       if (!sure) { // also where a product is not a number
-                        ix = (int)((ax / ext.x) * rxf); iy = (int)((ay / ext.y) * ryf); iz = (int)((az / ext.z) * rzf);
+                        px = (ax / ext.x) * rxf; py = (ay / ext.y) * ryf; pz = (az / ext.z) * rzf;
                       }
                     }
-                    ix = __builtin_elementwise_min(__builtin_elementwise_max(ix, 0), rx - 1);
-                    iy = __builtin_elementwise_min(__builtin_elementwise_max(iy, 0), ry - 1);
-                    iz = __builtin_elementwise_min(__builtin_elementwise_max(iz, 0), rz - 1);
-                    index[u] = bricked ? ((((iz >> 3) * nby + (iy >> 3)) * nbx + (ix >> 3)) << 9) +
-                                             (((iz & 7) << 6) | ((iy & 7) << 3) | (ix & 7))
-                                       : ix + iy * rx + iz * rx * ry;
+                    index[u] = cellIndex((int)__builtin_amdgcn_fmed3f(px, 0.0f, topX), (int)__builtin_amdgcn_fmed3f(py, 0.0f, topY),
+                                         (int)__builtin_amdgcn_fmed3f(pz, 0.0f, topZ));
                   }
                 }
                 unsigned int raw[4];
