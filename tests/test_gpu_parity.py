@@ -186,3 +186,21 @@ def test_empty_scene_is_background_only(oracle):
     gpu, ref = _both(sc, oracle)
     _compare(gpu, ref, "empty", min_exact=1.0)
     np.testing.assert_array_equal(gpu[2][:NA], ref[2][:NA])
+
+
+@pytest.mark.parametrize("camera", [(2.0, 3.0, 6.0), (3.5, 1.5, 6.0), (2.5, 2.0, 0.5), (1.5, 1.0, 6.0), (5.0, 1.5, 6.0)])
+@pytest.mark.parametrize("v1", [(2.0, 2.0, 2.0), (1.7, 2.2, 1.9)])
+def test_volume_march_on_skimming_rays_and_inexact_extents(oracle, camera, v1):
+    """The march skips sampleVolume's box tests on the stretch of a chord that is provably inside, and replaces the
+    division by the extent where it can: cameras in the plane of a face (rays that skim it), on an edge line, inside
+    the box, and a box whose extents are not powers of two must all give the oracle's frame bit for bit and its
+    sample count."""
+    res = (64, 48, 56)
+    vox = (scenes.synthetic_walnut(res) // 8).astype(np.uint8)
+    sc = scenes.config4(320, 180, voxels=vox, resolution=res)
+    sc.volumes = scenes._stack([scenes._volume((1.5, 1.0, -0.5), (0, 0, 0), v1, res, 0)], T.GPU_VOLUME)
+    sc.camera_pos = camera
+    gpu, ref = _both(sc, oracle)
+    _compare(gpu, ref, f"c4 camera {camera} extent {v1}", min_exact=1.0)
+    np.testing.assert_array_equal(gpu[2][:NA], ref[2][:NA])
+    assert int(ref[2][6]) > 0
