@@ -388,6 +388,26 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   P.waveLog = (mode == 2 && r->wantWaveLog) ? (unsigned long long *)r->dWaveLog.p : nullptr;
 
   if (P.numTiles <= 0) return PT_OK;
+  // A frame without solids: the camera rays, their march through the volume, the background.  That needs neither
+  // the state machine nor the tickets of the general kernel (tune bit 25 keeps it on the general kernel; the
+  // instrumented modes always are).
+  if (mode == 0 && pc->numSpheres == 0 && pc->numEllipsoids == 0 && pc->numVolumes > 0 && !(r->tune & (1 << 25))) {
+    P.volumeFilter = r->volumeFilter;
+    P.sampleIndex = r->sampleIndex;
+    if (r->accumulate && !fixed) {
+      PT_HIP_CHECK(r->dAccum.reserve((size_t)r->width * (size_t)std::max(r->localRows, 1) * sizeof(float4)));
+      P.accum = (float4 *)r->dAccum.p;
+      P.accumCount = r->accumCount + 1;
+    }
+    const int blocks = (P.numTiles + 3) / 4;
+    hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel, dim3(blocks), dim3(256), 0, stream, P);
+    PT_HIP_CHECK(hipGetLastError());
+    if (!fixed) r->lastSlot = slot;
+    r->lastBlocks = blocks;
+    r->lastThreads = 256;
+    r->lastLds = 1024;
+    return PT_OK;
+  }
   // The ordering pass pays off when pixels differ a lot in the number of rays
   // they cast (bounces) and looking at one pixel per tile is cheap next to the frame.
   const bool orderTiles =

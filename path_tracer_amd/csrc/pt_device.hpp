@@ -28,16 +28,11 @@
 
 #include "pt_frame.hpp"
 #include "pt_shaders.hpp"
+#include "pt_volume.hpp"
 
 namespace ptdev {
 
 // Where the dense sphere loop reads the sphere pairs from (compile-time choice per call site).
-// The lanes of the wave for which p holds, as a mask in scalar registers straight from the compare.
-__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-// How many lanes below this one are set in m (v_mbcnt_lo/hi: two instructions, no per-lane mask to keep).
-__device__ __forceinline__ int lanes_below(unsigned long long m) {
-  return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-}
 
 struct ScalarTag { static constexpr bool value = true; };
 struct LdsTag { static constexpr bool value = false; };
@@ -1084,190 +1079,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
           float volumeAlpha = 0.0f;
           if (L.numVolumes > 0) {
-            const float maxDist = hitAny ? bestT : kMaxDistance;
-            // intersectBox (:519-532)
-            const V3 invDir = mk3(1.0f / (curD.x + 1e-8f), 1.0f / (curD.y + 1e-8f), 1.0f / (curD.z + 1e-8f));
-            const V3 t0 = mul3(sub3(ld3(L.boxMin), rO), invDir);
-            const V3 t1 = mul3(sub3(ld3(L.boxMax), rO), invDir);
-            const V3 tmn = mk3(glmin(t0.x, t1.x), glmin(t0.y, t1.y), glmin(t0.z, t1.z));
-            const V3 tmx = mk3(glmax(t0.x, t1.x), glmax(t0.y, t1.y), glmax(t0.z, t1.z));
-            float tNear = glmax(glmax(tmn.x, tmn.y), tmn.z);
-            float tFar = glmin(glmin(tmx.x, tmx.y), tmx.z);
-            if (tFar >= tNear && tFar > 0.0f) {
-              tNear = glmax(tNear, 0.0f);
-              tFar = glmin(tFar, maxDist);
-              const float4 m4 = PT_MAT(L.volMaterial, 4);
-              const float absorptionCoeff = m4.w;
-              const float rxf = (float)L.res[0], ryf = (float)L.res[1], rzf = (float)L.res[2];
-              const int rx = L.res[0], ry = L.res[1], rz = L.res[2];
-              float t = tNear;
-              float acc = 0.0f;
-              int stepCount = 0;
-              const V3 vpos = ld3(L.volPos), lo = ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
-              const float rcpEx = L.rcpExtent[0], rcpEy = L.rcpExtent[1], rcpEz = L.rcpExtent[2];
-              const float cellTolX = 1.5f * 0x1p-22f * (float)L.res[0], cellTolY = 1.5f * 0x1p-22f * (float)L.res[1],
-                          cellTolZ = 1.5f * 0x1p-22f * (float)L.res[2];
-              const uint8_t *__restrict__ vox = P.voxels;
-              const bool exactExtent = L.exactExtent != 0;
-              const bool bricked = P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
-              const int nbx = P.brickX, nby = P.brickY;
-              if (L.volumeFilter == 1) {
-                // Trilinear extension: voxel centres at (i + 0.5) / res; lerp(a, b, t) =
-                // fma(t, b - a, a) along x, then y, then z on the byte values, then / 255.
-                const bool brk = P.brickX > 0;
-                const int bX = P.brickX, bY = P.brickY;
-                auto fetch = [&](int ix, int iy, int iz) -> float {
-                  const int id = brk ? ((((iz >> 3) * bY + (iy >> 3)) * bX + (ix >> 3)) << 9) +
-                                           (((iz & 7) << 6) | ((iy & 7) << 3) | (ix & 7))
-                                     : ix + iy * rx + iz * rx * ry;
-                  return (float)vox[id];
-                };
-                while (t < tFar && stepCount < 500) {
-                  const V3 pos = madd3(rO, t, curD);
-                  const V3 rel = sub3(pos, vpos);
-                  float density = 0.0f;
-                  if (!(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z)) {
-                    const float u[3] = {(rel.x - lo.x) / ext.x, (rel.y - lo.y) / ext.y, (rel.z - lo.z) / ext.z};
-                    const float rf[3] = {rxf, ryf, rzf};
-                    const int ri[3] = {rx, ry, rz};
-                    int i0[3], i1[3];
-                    float f[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                      const float p = u[a] * rf[a] - 0.5f;
-                      const float top = (float)(ri[a] - 1);
-                      float q = p < 0.0f ? 0.0f : (p > top ? top : p);
-                      if (q != q) q = 0.0f;
-                      i0[a] = (int)q;
-                      f[a] = q - (float)i0[a];
-                      i1[a] = i0[a] + 1 > ri[a] - 1 ? ri[a] - 1 : i0[a] + 1;
-                    }
-                    const float b000 = fetch(i0[0], i0[1], i0[2]), b100 = fetch(i1[0], i0[1], i0[2]);
-                    const float b010 = fetch(i0[0], i1[1], i0[2]), b110 = fetch(i1[0], i1[1], i0[2]);
-                    const float b001 = fetch(i0[0], i0[1], i1[2]), b101 = fetch(i1[0], i0[1], i1[2]);
-                    const float b011 = fetch(i0[0], i1[1], i1[2]), b111 = fetch(i1[0], i1[1], i1[2]);
-                    const float c00 = __builtin_fmaf(f[0], b100 - b000, b000), c10 = __builtin_fmaf(f[0], b110 - b010, b010);
-                    const float c01 = __builtin_fmaf(f[0], b101 - b001, b001), c11 = __builtin_fmaf(f[0], b111 - b011, b011);
-                    const float c0 = __builtin_fmaf(f[1], c10 - c00, c00), c1 = __builtin_fmaf(f[1], c11 - c01, c01);
-                    density = __builtin_fmaf(f[2], c1 - c0, c0) / 255.0f;
-                  }
-                  const float sampleAlpha = density * absorptionCoeff;
-                  acc = __builtin_fmaf(1.0f - acc, sampleAlpha, acc);
-                  t += 0.02f;
-                  stepCount++;
-                }
-              }
-              // Index of the (clamped) cell (ix, iy, iz).  Bricked: ((bz * nby + by) * nbx + bx) * 512 + (iz & 7) * 64 +
-              // (iy & 7) * 8 + (ix & 7) with b = i >> 3, written as the linear part ix + 8 iy + 64 iz plus what each
-              // whole brick adds along its axis; the factors fit 24 bits (the host keeps the linear layout otherwise).
-              const int brickRowStep = (nbx << 9) - 64, bricksPerSliceLess1 = nbx * nby - 1;
-              auto cellIndex = [&](int ix, int iy, int iz) -> int {
-                if (!bricked) return ix + iy * rx + iz * rx * ry;
-                int id = ix + (iy << 3) + (iz << 6);
-                id += __mul24(ix >> 3, 504);
-                id += __mul24(iy >> 3, brickRowStep);
-                return id + (__mul24(iz >> 3, bricksPerSliceLess1) << 9);
-              };
-              // clamp(int(p), 0, res - 1) as int(clamp(p, 0, res - 1)): the same integer for every p (the conversion
-              // truncates towards zero and saturates; res - 1 is a float exactly)
-              const float topX = rxf - 1.0f, topY = ryf - 1.0f, topZ = rzf - 1.0f;
-              // Samples a lane takes at tSafeA <= t <= tSafeB are inside the box whatever the rounding of their
-              // position, so they skip sampleVolume's six comparisons: the position is linear in t, both ends of that
-              // stretch lie inside every slab by a margin of 1e-5 of the magnitudes that enter the position (its
-              // rounding error is below 3e-7 of them), hence so does everything between them.  The stretch leaves out
-              // the first and the last hundredth of the chord, where the entry and exit faces are closer than that.
-              float tSafeA = kMaxDistance, tSafeB = -kMaxDistance;
-              if (exactExtent && L.volumeFilter != 1) {
-                const float ta = tNear + 0.01f, tb = tFar - 0.01f;
-                const V3 pa = sub3(madd3(rO, ta, curD), vpos), pb = sub3(madd3(rO, tb, curD), vpos);
-                const float mx = 1e-5f * (__builtin_fabsf(rO.x) + __builtin_fabsf(vpos.x) + __builtin_fabsf(lo.x) + __builtin_fabsf(hi.x) + tFar * __builtin_fabsf(curD.x));
-                const float my = 1e-5f * (__builtin_fabsf(rO.y) + __builtin_fabsf(vpos.y) + __builtin_fabsf(lo.y) + __builtin_fabsf(hi.y) + tFar * __builtin_fabsf(curD.y));
-                const float mz = 1e-5f * (__builtin_fabsf(rO.z) + __builtin_fabsf(vpos.z) + __builtin_fabsf(lo.z) + __builtin_fabsf(hi.z) + tFar * __builtin_fabsf(curD.z));
-                const bool inside = glmin(pa.x, pb.x) >= lo.x + mx && glmax(pa.x, pb.x) <= hi.x - mx &&
-                                    glmin(pa.y, pb.y) >= lo.y + my && glmax(pa.y, pb.y) <= hi.y - my &&
-                                    glmin(pa.z, pb.z) >= lo.z + mz && glmax(pa.z, pb.z) <= hi.z - mz;
-                if (ta <= tb && inside) { tSafeA = ta; tSafeB = tb; }
-              }
-              const float scaleX = rcpEx * rxf, scaleY = rcpEy * ryf, scaleZ = rcpEz * rzf; // exact where the extents are powers of two
-              // The march has no data-dependent exit, so four steps are taken per
-              // trip: their voxel loads are in flight together and the accumulation
-              // then runs in step order, exactly as one step per trip would.
-              while (t < tFar && stepCount < 500) {
-                float ts[4];
-                ts[0] = t;
-#pragma unroll
-                for (int u = 1; u < 4; ++u) ts[u] = ts[u - 1] + 0.02f;
-                if (ballot64(!(ts[0] >= tSafeA && ts[3] <= tSafeB && stepCount <= 496)) == 0ull) {
-                  // every marching lane of the wave has four samples inside the box: no tests, no masks
-                  // (ts[3] <= tSafeB < tFar: all four are taken; (a * rcpE) * res = a * (rcpE * res), both scalings exact)
-                  unsigned int raw[4];
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) {
-                    const V3 rel = sub3(madd3(rO, ts[u], curD), vpos);
-                    const int ix = (int)__builtin_amdgcn_fmed3f((rel.x - lo.x) * scaleX, 0.0f, topX);
-                    const int iy = (int)__builtin_amdgcn_fmed3f((rel.y - lo.y) * scaleY, 0.0f, topY);
-                    const int iz = (int)__builtin_amdgcn_fmed3f((rel.z - lo.z) * scaleZ, 0.0f, topZ);
-                    raw[u] = (unsigned int)vox[cellIndex(ix, iy, iz)];
-                  }
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(1.0f - acc, s_div255[raw[u]] * absorptionCoeff, acc);
-                  t = ts[3] + 0.02f;
-                  stepCount += 4;
-                  continue;
-                }
-                int index[4];
-                int n = 1;
-#pragma unroll
-                for (int u = 1; u < 4; ++u)
-                  if (n == u && ts[u] < tFar && stepCount + u < 500) n = u + 1;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  // sampleVolume (:485-517), nearest neighbour
-                  const V3 pos = madd3(rO, ts[u], curD);
-                  const V3 rel = sub3(pos, vpos);
-                  index[u] = -1;
-                  if (u < n && !(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z)) {
-                    // Only the integer part of ((rel - lo) / extent) * resolution is used.  With the reciprocal of the
-                    // extent (rounded once, from the host) the product differs from the shader's by less than
-                    // 1.26 * 2^-22 * resolution (one rounding of the reciprocal, one of each product, against one of
-                    // the quotient), so away from an integer by more than cellTol = 1.5 * 2^-22 * resolution it has the
-                    // same integer part; the few samples closer than that take the division.
-                    const float ax = rel.x - lo.x, ay = rel.y - lo.y, az = rel.z - lo.z;
-                    float px = (ax * rcpEx) * rxf, py = (ay * rcpEy) * ryf, pz = (az * rcpEz) * rzf;
-                    if (!exactExtent) { // where every extent is a power of two the product IS the shader's quotient
-                      const bool sure = __builtin_fabsf(__builtin_amdgcn_fractf(px) - 0.5f) < 0.5f - cellTolX &&
-                                        __builtin_fabsf(__builtin_amdgcn_fractf(py) - 0.5f) < 0.5f - cellTolY &&
-                                        __builtin_fabsf(__builtin_amdgcn_fractf(pz) - 0.5f) < 0.5f - cellTolZ;
-                      if (!sure) { // also where a product is not a number
-                        px = (ax / ext.x) * rxf; py = (ay / ext.y) * ryf; pz = (az / ext.z) * rzf;
-                      }
-                    }
-                    index[u] = cellIndex((int)__builtin_amdgcn_fmed3f(px, 0.0f, topX), (int)__builtin_amdgcn_fmed3f(py, 0.0f, topY),
-                                         (int)__builtin_amdgcn_fmed3f(pz, 0.0f, topZ));
-                  }
-                }
-                unsigned int raw[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) raw[u] = index[u] >= 0 ? (unsigned int)vox[index[u]] : 0u;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  if (u < n) {
-                    const float density = s_div255[raw[u]];
-                    const float sampleAlpha = density * absorptionCoeff;
-                    acc = __builtin_fmaf(1.0f - acc, sampleAlpha, acc);
-                  }
-                }
-                t = ts[n - 1] + 0.02f;
-                stepCount += n;
-              }
-              if (COUNT) cVoxel += (unsigned int)stepCount;
-              // mix(vec3(-1), materialColor*acc, float(acc >= 1e-4)) = x*(1-a) + y*a
-              const float a = (acc >= 0.0001f) ? 1.0f : 0.0f;
-              const float oma = 1.0f - a;
-              volX = -1.0f * oma + (m4.x * acc) * a;
-              volY = -1.0f * oma + (m4.y * acc) * a;
-              volZ = -1.0f * oma + (m4.z * acc) * a;
-            }
+            unsigned int marchSteps;
+            const V3 vol = march_volume(P, L, s_div255, [&]() -> float4 { return PT_MAT(L.volMaterial, 4); }, rO, curD,
+                                        hitAny ? bestT : kMaxDistance, marchSteps);
+            volX = vol.x; volY = vol.y; volZ = vol.z;
+            if (COUNT) cVoxel += marchSteps;
             if (volX >= 0.0f) { // :618-620
               volumeAlpha = glclamp(length3(mk3(volX, volY, volZ)) / length3(mk3(1.0f, 1.0f, 1.0f)), 0.0f, 1.0f);
             }
@@ -1375,19 +1191,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           }
         } while (0);
         if (step == GO_FINISH) do { // main() :703-704
-          float r = glclamp(fin.x, 0.0f, 1.0f), g = glclamp(fin.y, 0.0f, 1.0f), b = glclamp(fin.z, 0.0f, 1.0f);
-          if (P.accum) { // mean of the clamped samples so far
-            float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (L.accumCount > 1) sum = P.accum[outIdx];
-            sum = make_float4(sum.x + r, sum.y + g, sum.z + b, 0.0f);
-            P.accum[outIdx] = sum;
-            if (L.accumCount > 1) {
-              const float n = (float)L.accumCount;
-              r = sum.x / n; g = sum.y / n; b = sum.z / n;
-            }
-          }
-          P.outRgba8[outIdx] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
-          if (P.outF32) P.outF32[outIdx] = make_float4(r, g, b, 1.0f);
+          write_pixel(P, L.accumCount, outIdx, fin);
           state = ST_IDLE;
           step = GO_EMITTED;
         } while (0);

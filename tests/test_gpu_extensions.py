@@ -236,3 +236,27 @@ def test_launches_sized_by_the_streams_side_by_side_draw_the_same_frame():
             r.render(pc)
             np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want.view(np.uint32))
         r.shutdown()
+
+
+@pytest.mark.parametrize("options", [{}, {T.OPT_VOLUME_FILTER: 1}, {T.OPT_VOLUME_BRICKS: 0}])
+def test_frames_without_solids_are_the_same_on_either_kernel(options):
+    """A frame with a volume and no spheres or ellipsoids is drawn by a kernel of its own (camera ray, march,
+    background); tune bit 25 keeps it on the general kernel.  Same frame, bit for bit, also as one rank's bands
+    and as the mean of sub-pixel samples."""
+    sc = _small_volume_scene()
+    pc = sc.push_constants()
+    frames = []
+    for tune in (0, 1 << 25):
+        r = _renderer(sc, {**options, 100: tune})
+        f = [_frame(r, pc)[1].copy()]
+        assert (r.lastLaunch()[1] == 256 and r.lastLaunch()[2] == 1024) == (tune == 0)  # the volume kernel's launch
+        r.renderSamples(pc, 0, 3)
+        r.present()
+        f.append(r.readbackF32().copy())
+        r.setRowBands(16, 1, 3)
+        f.append(_frame(r, pc)[1].copy())
+        frames.append(f)
+        r.shutdown()
+    for a, b in zip(*frames):
+        assert a.shape == b.shape
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
