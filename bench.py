@@ -231,7 +231,23 @@ def measured_traffic(workload: str):
         return None
 
 
-def roofline_for(cnt, kernel_ms: float, traffic=None):
+def measured_cache(workload: str):
+    """L2 counters per launch of the timed kernel from the same profiling run (or None): requests, hits, misses of
+    the L2 (TCC) and the read requests the L1s (TCP) sent to it."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        import __graft_entry__ as g
+
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("source_hash") != g.source_hash():
+            return None
+        return doc.get(workload, {}).get("l2")
+    except (OSError, ValueError, KeyError, ImportError):
+        return None
+
+
+def roofline_for(cnt, kernel_ms: float, traffic=None, cache=None):
     flop = cnt[4] * FLOP_PER_SPHERE_TEST + cnt[5] * FLOP_PER_ELLIPSOID_TEST
     vox_bytes = cnt[6] * BYTES_PER_VOXEL_SAMPLE
     if flop > 0:
@@ -243,11 +259,23 @@ def roofline_for(cnt, kernel_ms: float, traffic=None):
                 "note": "17 flop per sphere test + 91 per ellipsoid test, brute force (rays x objects); "
                         "shading, sqrt/pow and hit-path work not counted"}
     achieved = vox_bytes / (kernel_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "pt_render_kernel",
-            "kernel_ms": round(kernel_ms, 4), "bytes_per_launch": float(vox_bytes),
-            "note": "requested bytes: 4 per nearest-neighbour voxel sample; the 41.7 MB volume is "
-                    "cache-resident after the first frame, so this is an L2/Infinity-Cache rate"}
+    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "pt_volume_frame_kernel",
+           "kernel_ms": round(kernel_ms, 4), "bytes_per_launch": float(vox_bytes),
+           "note": "algorithmic bytes: 4 per nearest-neighbour voxel sample, priced against HBM as the contract asks; "
+                   "the 41.7 MB volume stays in L2 / Infinity Cache after the first frame, so little of it is HBM traffic "
+                   "(hbm_GBs, from FETCH_SIZE x 2 + WRITE_SIZE) and the kernel is bound by vector-instruction issue "
+                   "(SQ counters in profiles/), not by any memory level"}
+    if traffic is not None:
+        out["hbm_GBs"] = round(traffic / (kernel_ms * 1e-3) / 1e9, 1)
+    if cache:
+        out["l2"] = dict(cache)
+        if cache.get("tcp_read_req"):
+            # every L1 miss asks the L2 for one 128-byte line (64-byte requests count as one too: an upper bound)
+            out["l2_requested_GBs"] = round(cache["tcp_read_req"] * 128.0 / (kernel_ms * 1e-3) / 1e9, 1)
+        if cache.get("req"):
+            out["l2_hit_rate"] = round(cache.get("hit", 0.0) / cache["req"], 4)
+    return out
 
 
 def cpu_baseline(scene, budget_s: float = 20.0):
@@ -388,7 +416,8 @@ def main():
                        if n_gpus > 1 else "single GPU", "device": dev_name, "compute_units": cus,
                        "launch": {"blocks": launch[0], "threads": launch[1], "lds_bytes": launch[2]}},
             "roofline": roofline_for(cnt / max(n_gpus, 1), kernel_ms,
-                                     measured_traffic(args.workload) if args.scale == 1.0 else None) if n_gpus == 1 else None,
+                                     measured_traffic(args.workload) if args.scale == 1.0 else None,
+                                     measured_cache(args.workload) if args.scale == 1.0 else None) if n_gpus == 1 else None,
         }
         result["frames_in_flight"] = fif
         result["streams_side_by_side"] = side_by_side
@@ -432,7 +461,8 @@ def main():
             rr.close()
             extras[name] = {"ms_per_frame": round(d / steps * 1e3, 4), "ms_per_frame_2_in_flight": round(d2 / steps * 1e3, 4),
                             "Mrays_per_s": round(c[0] / (d / steps) / 1e6, 2),
-                            "rays_per_frame": float(c[0]), "roofline": roofline_for(c, e / steps, measured_traffic(name))}
+                            "rays_per_frame": float(c[0]),
+                            "roofline": roofline_for(c, e / steps, measured_traffic(name), measured_cache(name))}
             if name == "c4":
                 extras[name]["Msamples_per_s"] = round(c[6] / (d / steps) / 1e6, 2)
                 # the trilinear quality mode (no counterpart in the reference): 8 voxel bytes per sample

@@ -1059,7 +1059,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     if (r->brickRes[0] != v.resolution_x || r->brickRes[1] != v.resolution_y || r->brickRes[2] != v.resolution_z) {
       const int nbx = (v.resolution_x + 7) / 8, nby = (v.resolution_y + 7) / 8, nbz = (v.resolution_z + 7) / 8;
       const long long brickBytes = (long long)nbx * nby * nbz * 512;
-      if (brickBytes <= 0x7fffffffll && nbx < 32768) { // the march indexes with 32-bit integers and 24-bit factors (512 nbx, nbx nby)
+      if (brickBytes <= 0x7fffffffll && (long long)nbx * nby < 32768) { // the march indexes with 32-bit integers and 24-bit factors (512 nbx nby)
         PT_HIP_CHECK(r->dBricks.reserve((size_t)brickBytes));
         const int grid = (int)std::min<long long>((brickBytes / 4 + 255) / 256, 65536);
         hipLaunchKernelGGL(ptdev::pt_brick_volume_kernel, dim3(grid), dim3(256), 0, r->stream[0], (const uint8_t *)r->dVoxels.p,

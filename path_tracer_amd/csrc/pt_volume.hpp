@@ -19,7 +19,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 // from (the same object, or its copy in LDS), s_div255: the table b / 255 for b = 0 .. 255 in LDS, materialRow4():
 // row 4 of the volume's material (colour, absorption coefficient).  Returns rayMarchVolume's colour ((-1,-1,-1): nothing there)
 // and the number of samples taken.
-template <class MaterialRow>
+// WIDE: trips of eight samples, two per packed operation, where every lane is inside the box (for a kernel with
+// registers to spare; the general kernel takes four, one at a time).
+template <bool WIDE, class MaterialRow>
 __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FrameParams &L, const float *s_div255, MaterialRow &&materialRow4,
                                            const V3 rO, const V3 curD, const float maxDist, unsigned int &steps) {
   float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
@@ -107,6 +109,17 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
         id += __mul24(iy >> 3, brickRowStep);
         return id + (__mul24(iz >> 3, bricksPerSliceLess1) << 9);
       };
+      // the same as an unsigned offset (the load then takes the base address from scalar registers), with one
+      // multiplication for the slices too
+      const int brickSliceStep = ((nbx * nby) << 9) - 512;
+      auto cellOffset = [&](int ix, int iy, int iz) -> unsigned int {
+        if (!bricked) return (unsigned int)(ix + iy * rx + iz * rx * ry);
+        int id = ix + (iy << 3) + (iz << 6);
+        id += __mul24(ix >> 3, 504);
+        id += __mul24(iy >> 3, brickRowStep);
+        id += __mul24(iz >> 3, brickSliceStep);
+        return (unsigned int)id;
+      };
       // clamp(int(p), 0, res - 1) as int(clamp(p, 0, res - 1)): the same integer for every p (the conversion
       // truncates towards zero and saturates; res - 1 is a float exactly)
       const float topX = rxf - 1.0f, topY = ryf - 1.0f, topZ = rzf - 1.0f;
@@ -131,27 +144,42 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       // The march has no data-dependent exit, so four steps are taken per
       // trip: their voxel loads are in flight together and the accumulation
       // then runs in step order, exactly as one step per trip would.
+      constexpr int kTrip = WIDE ? 8 : 4; // samples per trip while every lane is inside the box
       while (t < tFar && stepCount < 500) {
-        float ts[4];
+        float ts[kTrip];
         ts[0] = t;
 #pragma unroll
-        for (int u = 1; u < 4; ++u) ts[u] = ts[u - 1] + 0.02f;
-        if (ballot64(!(ts[0] >= tSafeA && ts[3] <= tSafeB && stepCount <= 496)) == 0ull) {
-          // every marching lane of the wave has four samples inside the box: no tests, no masks
-          // (ts[3] <= tSafeB < tFar: all four are taken; (a * rcpE) * res = a * (rcpE * res), both scalings exact)
-          unsigned int raw[4];
+        for (int u = 1; u < kTrip; ++u) ts[u] = ts[u - 1] + 0.02f;
+        if (ballot64(!(ts[0] >= tSafeA && ts[kTrip - 1] <= tSafeB && stepCount <= 500 - kTrip)) == 0ull) {
+          // every marching lane of the wave has kTrip samples inside the box: no tests, no masks
+          // (ts[kTrip - 1] <= tSafeB < tFar: all are taken; (a * rcpE) * res = a * (rcpE * res), both scalings exact)
+          unsigned int raw[kTrip];
+          if (WIDE) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const V3 rel = sub3(madd3(rO, ts[u], curD), vpos);
-            const int ix = (int)__builtin_amdgcn_fmed3f((rel.x - lo.x) * scaleX, 0.0f, topX);
-            const int iy = (int)__builtin_amdgcn_fmed3f((rel.y - lo.y) * scaleY, 0.0f, topY);
-            const int iz = (int)__builtin_amdgcn_fmed3f((rel.z - lo.z) * scaleZ, 0.0f, topZ);
-            raw[u] = (unsigned int)vox[cellIndex(ix, iy, iz)];
+            for (int u = 0; u < kTrip; u += 2) { // two samples per packed operation
+              const f2 tt = mk2(ts[u], ts[u + 1]);
+              const f2 qx = ((fma2(tt, mk2(curD.x, curD.x), mk2(rO.x, rO.x)) - mk2(vpos.x, vpos.x)) - mk2(lo.x, lo.x)) * mk2(scaleX, scaleX);
+              const f2 qy = ((fma2(tt, mk2(curD.y, curD.y), mk2(rO.y, rO.y)) - mk2(vpos.y, vpos.y)) - mk2(lo.y, lo.y)) * mk2(scaleY, scaleY);
+              const f2 qz = ((fma2(tt, mk2(curD.z, curD.z), mk2(rO.z, rO.z)) - mk2(vpos.z, vpos.z)) - mk2(lo.z, lo.z)) * mk2(scaleZ, scaleZ);
+              raw[u] = (unsigned int)vox[cellOffset((int)__builtin_amdgcn_fmed3f(qx.x, 0.0f, topX), (int)__builtin_amdgcn_fmed3f(qy.x, 0.0f, topY),
+                                                   (int)__builtin_amdgcn_fmed3f(qz.x, 0.0f, topZ))];
+              raw[u + 1] = (unsigned int)vox[cellOffset((int)__builtin_amdgcn_fmed3f(qx.y, 0.0f, topX), (int)__builtin_amdgcn_fmed3f(qy.y, 0.0f, topY),
+                                                       (int)__builtin_amdgcn_fmed3f(qz.y, 0.0f, topZ))];
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < kTrip; ++u) {
+              const V3 rel = sub3(madd3(rO, ts[u], curD), vpos);
+              const int ix = (int)__builtin_amdgcn_fmed3f((rel.x - lo.x) * scaleX, 0.0f, topX);
+              const int iy = (int)__builtin_amdgcn_fmed3f((rel.y - lo.y) * scaleY, 0.0f, topY);
+              const int iz = (int)__builtin_amdgcn_fmed3f((rel.z - lo.z) * scaleZ, 0.0f, topZ);
+              raw[u] = (unsigned int)vox[cellIndex(ix, iy, iz)];
+            }
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(1.0f - acc, s_div255[raw[u]] * absorptionCoeff, acc);
-          t = ts[3] + 0.02f;
-          stepCount += 4;
+          for (int u = 0; u < kTrip; ++u) acc = __builtin_fmaf(1.0f - acc, s_div255[raw[u]] * absorptionCoeff, acc);
+          t = ts[kTrip - 1] + 0.02f;
+          stepCount += kTrip;
           continue;
         }
         int index[4];
@@ -245,7 +273,7 @@ __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams 
   V3 fin = mk3(0, 0, 0);
   float thr = 1.0f;
   unsigned int steps;
-  const V3 vol = march_volume(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
+  const V3 vol = march_volume<true>(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
                               kMaxDistance, steps);
   float volumeAlpha = 0.0f;
   if (vol.x >= 0.0f) volumeAlpha = glclamp(length3(vol) / length3(mk3(1.0f, 1.0f, 1.0f)), 0.0f, 1.0f); // :618-620

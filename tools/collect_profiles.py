@@ -22,11 +22,15 @@ sys.path.insert(0, HERE)
 import pmc_summary  # noqa: E402
 
 
-def kernel_counter(db, counter, kernel_like="pt_render_kernel<0,"):
+# the timed (uninstrumented) kernel of each workload: the general frame kernel, or the kernel for frames without solids
+TIMED_KERNELS = ("pt_render_kernel<0,", "pt_volume_frame_kernel")
+
+
+def kernel_counter(db, counter, kernels=TIMED_KERNELS):
     con = sqlite3.connect(db)
     acc, disp = 0.0, set()
     for k, did, cname, val in con.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
-        if kernel_like in k and cname == counter:
+        if any(name in k for name in kernels) and cname == counter:
             acc += val
             disp.add(did)
     return acc / max(len(disp), 1)
@@ -46,7 +50,7 @@ def main():
         pmc_summary.main()
     with open(os.path.join(out, f"{rnd}_kernel_trace.txt"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras --frames-in-flight 1\n")
-        f.write("# (default workload c2: 12 launches of pt_render_kernel<0,...> = 2 warm-up + 10 timed; <1,...> and <2,...> are the\n")
+        f.write("# (default workload c2: 12 launches of pt_render_kernel<0,...> = 2 warm-up + 10 timed (c4: pt_volume_frame_kernel); <1,...> and <2,...> are the\n")
         f.write("#  instrumented, untimed counting and phase-timing launches)\n")
         f.write(buf.getvalue())
         for wl in ("c3", "c4"):
@@ -77,13 +81,18 @@ def main():
         if fdb and wdb:
             traffic[wl] = {"fetch_bytes": kernel_counter(fdb[0], "FETCH_SIZE") * 1024.0,
                            "write_bytes": kernel_counter(wdb[0], "WRITE_SIZE") * 1024.0}
+            ldb = glob.glob(os.path.join(src, f"pmc_l2_{wl}", "*_results.db"))
+            if ldb:
+                traffic[wl]["l2"] = {"req": kernel_counter(ldb[0], "TCC_REQ_sum"), "hit": kernel_counter(ldb[0], "TCC_HIT_sum"),
+                                     "miss": kernel_counter(ldb[0], "TCC_MISS_sum"),
+                                     "tcp_read_req": kernel_counter(ldb[0], "TCP_TCC_READ_REQ_sum")}
     # the build these passes ran on: bench.py only quotes a traffic.json measured on the build it is running
     try:
         with open(os.path.join(src, "source_hash.txt")) as f:
             traffic["source_hash"] = f.read().strip()
     except OSError:
         traffic["source_hash"] = None
-    traffic["unit"] = "bytes per launch of pt_render_kernel<0,...>; FETCH_SIZE and WRITE_SIZE as rocprofv3 reports them (KiB x 1024), uncorrected"
+    traffic["unit"] = "bytes per launch of the timed kernel (pt_render_kernel<0,...>, or pt_volume_frame_kernel for c4); FETCH_SIZE and WRITE_SIZE as rocprofv3 reports them (KiB x 1024), uncorrected"
     for name in (f"{rnd}_traffic.json", "traffic.json"):  # traffic.json = the latest, read by bench.py
         with open(os.path.join(out, name), "w") as f:
             json.dump(traffic, f, indent=1)
