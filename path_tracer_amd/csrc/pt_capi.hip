@@ -522,20 +522,22 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
     PT_HIP_CHECK(hipGetLastError());
   }
   dim3 grid(blocks), block(threads);
-#define PT_LAUNCH_K(MODE_, LDS_, POOLED_)                                                                    \
-  {                                                                                                          \
-    if (LDS_)                                                                                                \
-      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, LDS_, POOLED_>,          \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));          \
-    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, LDS_, POOLED_>), grid, block, ldsBytes, stream, P);   \
+#define PT_LAUNCH_K(MODE_, LDS_, POOLED_, VOLUME_)                                                                     \
+  {                                                                                                                    \
+    if (LDS_)                                                                                                          \
+      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, LDS_, POOLED_, VOLUME_>,           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                    \
+    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, LDS_, POOLED_, VOLUME_>), grid, block, ldsBytes, stream, P);    \
   }
-#define PT_LAUNCH(MODE_)                                                                                     \
-  if (useLds) {                                                                                              \
-    if (P.coop) PT_LAUNCH_K(MODE_, true, true) else PT_LAUNCH_K(MODE_, true, false)                          \
-  } else {                                                                                                   \
-    if (P.coop) PT_LAUNCH_K(MODE_, false, true) else PT_LAUNCH_K(MODE_, false, false)                        \
+#define PT_LAUNCH(MODE_, VOLUME_)                                                                                      \
+  if (useLds) {                                                                                                        \
+    if (P.coop) PT_LAUNCH_K(MODE_, true, true, VOLUME_) else PT_LAUNCH_K(MODE_, true, false, VOLUME_)                  \
+  } else {                                                                                                             \
+    if (P.coop) PT_LAUNCH_K(MODE_, false, true, VOLUME_) else PT_LAUNCH_K(MODE_, false, false, VOLUME_)                \
   }
-  if (mode == 1) { PT_LAUNCH(1) } else if (mode == 2) { PT_LAUNCH(2) } else { PT_LAUNCH(0) }
+  // the production kernel exists with and without the volume march; the instrumented ones always carry it
+  if (mode == 1) { PT_LAUNCH(1, true) } else if (mode == 2) { PT_LAUNCH(2, true) }
+  else if (pc->numVolumes > 0) { PT_LAUNCH(0, true) } else { PT_LAUNCH(0, false) }
 #undef PT_LAUNCH
 #undef PT_LAUNCH_K
   PT_HIP_CHECK(hipGetLastError());

@@ -55,7 +55,9 @@ enum : int {
 // apart from MODE 1, whose extra registers would distort the timing).
 // POOLED: the variant for scenes whose frames end in pooled passes (P.coop: many spheres); the other variant is the one
 // that can fan lighting rays out (P.fanOut).  The host launches the one that matches; each carries only its own code.
-template <int MODE, bool LDS_OBJECTS, bool POOLED>
+// VOLUME false: the variant for scenes without a volume, compiled without the march (the registers it would hold
+// through the shading sweep go to the rest of the kernel).
+template <int MODE, bool LDS_OBJECTS, bool POOLED, bool VOLUME = true>
 __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   const bool poolingOn = POOLED && P.coop != 0;
   const bool fanOutOn = !POOLED && P.fanOut != 0;
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   const int nThreads = (int)blockDim.x, nWaves = (int)(blockDim.x >> 6), waveInBlock = (int)(threadIdx.x >> 6);
   // density of a voxel byte: the 256 quotients b / 255 (the IEEE division the shader does per sample), tabulated
   float *const s_div255 = (float *)((char *)paramsLds + ((sizeof(FrameParams) + 15) & ~(size_t)15));
-  if (P.numVolumes > 0)
+  if (VOLUME && P.numVolumes > 0)
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_div255[i] = (float)i / 255.0f;
   char *const coopBase = (char *)(s_div255 + 256);
   int *const c_ctrl = (int *)coopBase; // [0] switch, [1..2] pooled-ray count, [3..4] any ray left, [5..6] exact-ray count (by parity)
@@ -1078,7 +1080,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           // --- rayMarchVolume(currentRay, hit ? rec.t : MAX_DISTANCE, 0) (:534-585) ---
           float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
           float volumeAlpha = 0.0f;
-          if (L.numVolumes > 0) {
+          if (VOLUME && L.numVolumes > 0) {
             unsigned int marchSteps;
             const V3 vol = march_volume<false>(P, L, s_div255, [&]() -> float4 { return PT_MAT(L.volMaterial, 4); }, rO, curD,
                                         hitAny ? bestT : kMaxDistance, marchSteps);
