@@ -351,6 +351,7 @@ def main():
             torch.cuda.set_device(local_rank)
             dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:  # rccl: the library talks to RCCL itself; the process group is the control plane only
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the ranks meet on the loopback interface
             dist_mod.init_process_group("gloo")
         torch_mod, dist = torch, dist_mod
     if args.gpus != world and rank == 0 and world > 1:
