@@ -49,6 +49,9 @@ def test_static_entry_point_matches_pt_render_twice_in_a_row():
     _both(scenes.config2(160, 90, n_spheres=9, n_ellipsoids=3, max_depth=4), torch, with_float=False)
     # and a scene that takes the pooled variant of the kernel plus the volume march
     _both(scenes.config3(192, 108, n_spheres=300, max_depth=4), torch, with_float=True)
+    # a frame without solids: the volume kernel, which uses none of the scratch
+    res = (40, 30, 36)
+    _both(scenes.config4(200, 120, voxels=(scenes.synthetic_walnut(res) // 8).astype(np.uint8), resolution=res), torch, with_float=True)
 
 
 def test_static_entry_point_rejects_what_it_cannot_hold():
