@@ -48,7 +48,10 @@ enum {
                                frame at a time.  More than 2 pays where a frame is short against
                                its longest chain of dependent rays (a rank's share of a frame
                                split over many GPUs).  A caller's stream or output buffers given
-                               for slot 0 only imply 1.                                           */
+                               for slot 0 only imply 1.  With n >= 2 the caller is taken to keep n
+                               frames queued: a frame with few tiles per wave is launched on a part
+                               of the compute units only (see pt_stream_concurrency), which costs
+                               latency if the frames are in fact drawn one by one.                 */
   PT_OPT_HONOUR_MAX_DEPTH = 7, /* 0 (default): every frame runs 10 bounces whatever
                                PushConstants.maxDepth says, as the reference shader does
                                (it ignores the field, shaders/raytrace.comp:603-605);

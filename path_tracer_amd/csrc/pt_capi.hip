@@ -148,6 +148,9 @@ struct PtRenderer {
   //   bits 5-7    unit-direction tolerance x 2^n        bits 8-15   sparse-mode lane threshold + 1
   //   bit 24      the tolerance also for directions shorter than 1 (as before the loop took those)
   //   bits 16-20  waves per workgroup, bits 21-23 workgroups per CU (0: chosen from the scene size)
+  //   bit 25      frames without solids on the general kernel, not the volume kernel
+  //   bit 26      (instrumented phase kernel) per-phase and per-ticket clock stamps
+  //   bits 27-29  n > 0: launch 1/2^(n-1) of the resident workgroups whatever is in flight
   int tune = 0;
   void *extRgba8[kMaxSlots] = {}, *extF32[kMaxSlots] = {}; // caller-owned output per slot (pt_set_output: slot 0, pt_set_slot)
   bool floatOutput = true;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/round_probes.sh <tag> — the side measurements quoted in DESIGN.md (band shares, launch sizes of frames in flight,
+# tools/round_probes.sh <tag> — side measurements of a build (band shares, launch sizes of frames in flight,
 # wave timelines, rank 0's exchange cost, what other libraries in the process do to the streams), one log each under
 # gpurun_out/<tag>/; run on the GPU box after tools/round_profile.sh.
 set -u
