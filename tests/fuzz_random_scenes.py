@@ -1,5 +1,5 @@
 """Long differential run, by hand: python tests/fuzz_random_scenes.py [first_seed] [count]
-Random scenes of tests/test_gpu_random_scenes.py (both generators) against the oracle; prints the seeds that differ."""
+Random scenes of tests/test_gpu_random_scenes.py (all three generators) against the oracle; prints the seeds that differ."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ oracle_py.lib()
 orc = oracle_py
 bad = []
 for seed in range(first, first + count):
-    sc = G.random_hall_of_mirrors(seed) if seed % 10 == 0 else G.random_scene(seed)
+    sc = G.random_hall_of_mirrors(seed) if seed % 10 == 0 else G.random_volume_frame(seed) if seed % 10 == 5 else G.random_scene(seed)
     r = HipRenderer(); assert r.initialize(sc.width, sc.height)
     r.setScene(sc); pc = sc.push_constants()
     r.render(pc); r.present()

@@ -172,3 +172,59 @@ def test_random_scene_volume_modes_match_the_oracle(oracle, seed):
     both_nan = np.isnan(gf) & np.isnan(rf)
     okf = ((np.abs(gf - rf) <= 1e-4 * np.maximum(np.abs(rf), 1e-2)) | both_nan).all(axis=-1)
     assert float((d8 <= 1).mean()) >= 0.999 and float(okf.mean()) >= 0.999, (sc.name, bricks, trilinear, samples)
+
+
+def random_volume_frame(seed: int) -> scenes.Scene:
+    """A volume and no solids (the frames the volume kernel draws): extents that are powers of two (the march's trips
+    without box tests) or not, boxes from a fraction of a unit to 16 units (the 500-step limit), cameras far off, in
+    the plane of a face, on an edge line and inside the box, absorption up to where the sum overshoots."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    w, h = int(rng.integers(40, 200)), int(rng.integers(30, 120))
+    sc = scenes.Scene(width=w, height=h, name=f"volume{seed}")
+    pow2 = rng.random() < 0.7
+    ext = tuple(float(rng.choice([0.5, 1.0, 2.0, 4.0, 16.0])) if pow2 else u(0.4, 5.0) for _ in range(3))
+    # the camera looks at (2, 1.5, 0): keep the box around that point
+    pos = (2.0 - ext[0] * u(0.2, 0.8), 1.5 - ext[1] * u(0.2, 0.8), 0.0 - ext[2] * u(0.2, 0.8))
+    res = (int(rng.integers(3, 70)), int(rng.integers(3, 70)), int(rng.integers(3, 70)))
+    sc.materials = scenes._materials([Material.Volumetric((u(0.1, 1), u(0.1, 1), u(0.1, 1)), u(0.2, 8.0))])
+    sc.volumes = scenes._stack([scenes._volume(pos, (0, 0, 0), ext, res, 0)], T.GPU_VOLUME)
+    sc.voxels = (scenes.synthetic_walnut(res) // int(rng.integers(1, 12))).astype(np.uint8)
+    kind = int(rng.integers(5))
+    if kind == 0:    # inside the box
+        sc.camera_pos = tuple(pos[i] + ext[i] * u(0.1, 0.9) for i in range(3))
+    elif kind == 1:  # in the plane of the top face
+        sc.camera_pos = (2.0 + u(-6, 6), pos[1] + ext[1], u(3, 9))
+    elif kind == 2:  # on the line of an edge
+        sc.camera_pos = (pos[0] + ext[0], pos[1] + ext[1], u(3, 9))
+    else:
+        ang = u(0, 2 * np.pi)
+        sc.camera_pos = (2.0 + u(2, 12) * np.cos(ang), u(-3, 6), u(2, 12) * np.sin(ang))
+    sc.bg_top, sc.bg_bottom = (u(0, 1), u(0, 1), u(0, 1)), (u(0, 1), u(0, 1), u(0, 1))
+    sc.max_depth = int(rng.integers(1, 11))
+    return sc
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_volume_frame_matches_the_oracle(oracle, seed):
+    """Bit for bit: no pow or cos on this path.  Bricked or linear voxels, nearest or trilinear filter by seed."""
+    from path_tracer_amd import HipRenderer
+
+    sc = random_volume_frame(5000 + seed)
+    bricks, trilinear = seed & 1, int(seed % 5 == 3)
+    r = HipRenderer()
+    assert r.initialize(sc.width, sc.height)
+    r.setOption(T.OPT_VOLUME_BRICKS, bricks)
+    r.setOption(T.OPT_VOLUME_FILTER, trilinear)
+    r.setScene(sc)
+    pc = sc.push_constants()
+    r.render(pc)
+    r.present()
+    gf = r.readbackF32()
+    assert r.lastLaunch()[2] == 1024  # the volume kernel drew it
+    cnt = r.renderCounted(pc)
+    r.shutdown()
+    r8, rf, rc = oracle.render(sc, nthreads=8, volume_filter=trilinear)
+    np.testing.assert_array_equal(cnt[:NA], rc[:NA])
+    same = (gf.view(np.uint32) == rf.view(np.uint32)) | (np.isnan(gf) & np.isnan(rf))
+    assert same.all(), (sc.name, bricks, trilinear, float(same.all(axis=-1).mean()))
