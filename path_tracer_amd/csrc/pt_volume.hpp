@@ -63,6 +63,68 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
                              : ix + iy * rx + iz * rx * ry;
           return (float)vox[id];
         };
+        // WIDE: kTri samples per trip, their voxel loads in flight together; every sample computes its (clamped, hence
+        // valid) cells and loads them, the box test and the loop's own condition select afterwards what counts.
+        // Each cell index is a sum of one term per axis (for the bricked copy: i + (i >> 3) * 504, 8 i + (i >> 3) *
+        // (512 nbx - 64), 64 i + (i >> 3) * (512 nbx nby - 512)), so the eight cells of a sample share six terms.
+        constexpr int kTri = 2; // four per trip need 96 registers instead of 53 and are no faster
+        while (WIDE && t < tFar && stepCount < 500) {
+          const int rowStep = (bX << 9) - 64, sliceStep = ((bX * bY) << 9) - 512; // fit 24 bits (or the copy is linear)
+          float tsT[kTri];
+          tsT[0] = t;
+#pragma unroll
+          for (int s = 1; s < kTri; ++s) tsT[s] = tsT[s - 1] + 0.02f;
+          unsigned int cell[kTri][8];
+          float f[kTri][3];
+          bool inside[kTri];
+#pragma unroll
+          for (int s = 0; s < kTri; ++s) {
+            const V3 rel = sub3(madd3(rO, tsT[s], curD), vpos);
+            inside[s] = !(rel.x < lo.x || rel.y < lo.y || rel.z < lo.z || rel.x > hi.x || rel.y > hi.y || rel.z > hi.z);
+            // where every extent is a power of two the product with its reciprocal is the quotient
+            const float u[3] = {exactExtent ? (rel.x - lo.x) * rcpEx : (rel.x - lo.x) / ext.x,
+                                exactExtent ? (rel.y - lo.y) * rcpEy : (rel.y - lo.y) / ext.y,
+                                exactExtent ? (rel.z - lo.z) * rcpEz : (rel.z - lo.z) / ext.z};
+            const float rf[3] = {rxf, ryf, rzf};
+            const int ri[3] = {rx, ry, rz};
+            int term[2][3]; // [lower / upper cell][axis]
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              const float p = u[a] * rf[a] - 0.5f;
+              const float top = (float)(ri[a] - 1);
+              float q = p < 0.0f ? 0.0f : (p > top ? top : p);
+              if (q != q) q = 0.0f;
+              const int i0 = (int)q;
+              f[s][a] = q - (float)i0;
+              const int i1 = i0 + 1 > ri[a] - 1 ? ri[a] - 1 : i0 + 1;
+              const int lin = a == 0 ? 1 : (a == 1 ? rx : rx * ry);
+              const int shift = 3 * a, step = a == 0 ? 504 : (a == 1 ? rowStep : sliceStep);
+              term[0][a] = brk ? (i0 << shift) + __mul24(i0 >> 3, step) : i0 * lin;
+              term[1][a] = brk ? (i1 << shift) + __mul24(i1 >> 3, step) : i1 * lin;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) cell[s][c] = (unsigned int)(term[c & 1][0] + term[(c >> 1) & 1][1] + term[c >> 2][2]);
+          }
+          float b[kTri][8];
+#pragma unroll
+          for (int s = 0; s < kTri; ++s)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[s][c] = (float)vox[cell[s][c]];
+          const int stepsBefore = stepCount;
+#pragma unroll
+          for (int s = 0; s < kTri; ++s) {
+            // t only grows, so a sample that is not taken ends the lane's march (the ones after it are not taken either)
+            const bool taken = s == 0 || (tsT[s] < tFar && stepsBefore + s < 500);
+            const float c00 = __builtin_fmaf(f[s][0], b[s][1] - b[s][0], b[s][0]), c10 = __builtin_fmaf(f[s][0], b[s][3] - b[s][2], b[s][2]);
+            const float c01 = __builtin_fmaf(f[s][0], b[s][5] - b[s][4], b[s][4]), c11 = __builtin_fmaf(f[s][0], b[s][7] - b[s][6], b[s][6]);
+            const float c0 = __builtin_fmaf(f[s][1], c10 - c00, c00), c1 = __builtin_fmaf(f[s][1], c11 - c01, c01);
+            const float density = inside[s] ? __builtin_fmaf(f[s][2], c1 - c0, c0) / 255.0f : 0.0f;
+            const float next = __builtin_fmaf(1.0f - acc, density * absorptionCoeff, acc);
+            acc = taken ? next : acc;
+            stepCount += taken ? 1 : 0;
+          }
+          t = tsT[kTri - 1] + 0.02f;
+        }
         while (t < tFar && stepCount < 500) {
           const V3 pos = madd3(rO, t, curD);
           const V3 rel = sub3(pos, vpos);
