@@ -263,9 +263,9 @@ def roofline_for(cnt, kernel_ms: float, traffic=None, cache=None):
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "pt_volume_frame_kernel",
            "kernel_ms": round(kernel_ms, 4), "bytes_per_launch": float(vox_bytes),
            "note": "algorithmic bytes: 4 per nearest-neighbour voxel sample, priced against HBM as the contract asks; "
-                   "the 41.7 MB volume stays in L2 / Infinity Cache after the first frame, so little of it is HBM traffic "
-                   "(hbm_GBs, from FETCH_SIZE x 2 + WRITE_SIZE) and the kernel is bound by vector-instruction issue "
-                   "(SQ counters in profiles/), not by any memory level"}
+                   "what HBM really delivers per frame is in hbm_GBs (FETCH_SIZE x 2 + WRITE_SIZE: the 41.7 MB volume about "
+                   "twice, once per group of L2s, plus the frame), what the L1s ask of the L2 in l2_requested_GBs; the kernel "
+                   "is bound by vector-instruction issue (SQ counters in profiles/), not by any memory level"}
     if traffic is not None:
         out["hbm_GBs"] = round(traffic / (kernel_ms * 1e-3) / 1e9, 1)
     if cache:
