@@ -1,6 +1,15 @@
 """The N > 1 path on CPU: two gloo ranks each render their interleaved row
 bands (with the CPU oracle standing in for the device kernel), gather to rank 0
-and de-interleave; the result must equal the single-process frame."""
+and de-interleave; the result must equal the single-process frame.
+
+What this covers: the band arithmetic (which rows a rank owns, the compact
+band-major layout, the padded stride of the gather buffer), the gather through
+torch.distributed and the host-side de-interleave, with two real processes.
+What it does not cover: the device kernel drawing a rank's share, the device
+de-interleave kernel, the RCCL gather inside the library and the frame slots
+and streams of the bench; tests/test_gpu_multigpu.py runs those on one GPU
+(every rank's share of 2, 3 and 8 ranks in turn, RCCL and torch-nccl with a
+world of one)."""
 import os
 import socket
 import sys
