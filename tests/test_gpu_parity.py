@@ -204,3 +204,26 @@ def test_volume_march_on_skimming_rays_and_inexact_extents(oracle, camera, v1):
     _compare(gpu, ref, f"c4 camera {camera} extent {v1}", min_exact=1.0)
     np.testing.assert_array_equal(gpu[2][:NA], ref[2][:NA])
     assert int(ref[2][6]) > 0
+
+
+def test_largest_frames_index_without_overflow(oracle):
+    """A 16384 x 8192 frame (2^27 pixels, 2 M tiles; pt_create takes up to 2^30 pixels): rows from the top, the
+    middle and the bottom of the frame against the oracle, and the ragged 8190-row variant's last rows."""
+    from path_tracer_amd import HipRenderer
+
+    for W, H in ((16384, 8192), (4099, 8190)):
+        sc = scenes.config1(W, H)
+        r = HipRenderer()
+        assert r.initialize(W, H)
+        r.setOption(T.OPT_FLOAT_OUTPUT, 0)
+        r.setScene(sc)
+        r.render(sc.push_constants())
+        r.present()
+        g8 = r.readbackRGBA8()
+        r.shutdown()
+        assert g8.shape == (H, W, 4)
+        for r0 in (0, H // 2 - 3, H - 5):
+            ref = oracle.render(sc, rows=(r0, r0 + 5), nthreads=16, want_f32=False)[0]
+            d = np.abs(g8[r0:r0 + 5].astype(np.int16) - ref[r0:r0 + 5].astype(np.int16)).max(axis=-1)
+            assert float((d <= 1).mean()) >= 0.999, (W, H, r0, float((d <= 1).mean()))
+            assert g8[r0:r0 + 5, :, 3].min() == 255  # every pixel of the rows was written
