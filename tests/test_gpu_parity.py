@@ -227,3 +227,32 @@ def test_largest_frames_index_without_overflow(oracle):
             d = np.abs(g8[r0:r0 + 5].astype(np.int16) - ref[r0:r0 + 5].astype(np.int16)).max(axis=-1)
             assert float((d <= 1).mean()) >= 0.999, (W, H, r0, float((d <= 1).mean()))
             assert g8[r0:r0 + 5, :, 3].min() == 255  # every pixel of the rows was written
+
+
+@pytest.mark.parametrize("res", [(2048, 2048, 4), (520, 300, 700)])
+def test_large_volumes_bricked_or_not(oracle, res):
+    """109 M voxels in 8x8x8 bricks (65 x 38 x 88 of them), and a flat 2048 x 2048 x 4 volume whose bricks per slice
+    would not fit the march's 24-bit factors, so that it stays linear: both frames bit for bit, with and without solids."""
+    from path_tracer_amd import HipRenderer
+
+    vox = np.random.default_rng(7).integers(0, 24, size=res[0] * res[1] * res[2], dtype=np.uint8)
+    for with_sphere in (False, True):
+        sc = scenes.config4(200, 112, voxels=vox, resolution=res)
+        if with_sphere:
+            mats = [scenes.Material.Volumetric((0.8, 0.6, 0.4), 8.0), scenes.Material.Mirror((0.9, 0.9, 0.9), 0.8)]
+            sc.materials = scenes._materials(mats)
+            sc.spheres = scenes._stack([scenes._sphere((2.2, 1.6, 0.4), 0.5, 1)], T.GPU_SPHERE)
+            sc.max_depth = 3
+        r = HipRenderer()
+        assert r.initialize(sc.width, sc.height)
+        r.setScene(sc)
+        pc = sc.push_constants()
+        r.render(pc)
+        r.present()
+        gf = r.readbackF32()
+        cnt = r.renderCounted(pc)
+        r.shutdown()
+        _, rf, rc = oracle.render(sc, nthreads=16)
+        np.testing.assert_array_equal(cnt[:NA], rc[:NA])
+        same = (gf.view(np.uint32) == rf.view(np.uint32)) | (np.isnan(gf) & np.isnan(rf))
+        assert same.all(), (res, with_sphere, float(same.all(axis=-1).mean()))
