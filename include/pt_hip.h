@@ -185,7 +185,8 @@ int pt_stream_concurrency(PtRenderer *r, int *streams);
 
 /* Profiling aid: draws one frame with the kernel that stamps the clock three times per wave and
  * returns, for wave i of the launch, out[4i .. 4i+3] = the 100 MHz clock (s_memrealtime) at its start, when it found the tile tickets
- * drained, at its exit, and the number of passes it made.  *num_waves = waves of the launch. */
+ * drained, at its exit, and in the fourth word the number of passes it made (low 32 bits) and how many of them it had
+ * made when it found the tickets drained (high 32 bits).  *num_waves = waves of the launch. */
 int pt_wave_timeline(PtRenderer *r, const PtPushConstants *pc, uint64_t *out, size_t capacity_waves, int *num_waves);
 
 /* pt_render without any allocation.  No counterpart in the reference; it is for

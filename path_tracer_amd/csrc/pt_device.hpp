@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
   unsigned long long cycTicket = 0, nTickets = 0, tExhausted = 0, tStart = 0;
   unsigned long long rtStart = 0, rtDry = 0; // s_memrealtime stamps (one clock for the whole chip, unlike s_memtime)
-  unsigned int nPasses = 0;
+  unsigned int nPasses = 0, passesAtDry = 0;
   // MODE 2 always stamps a wave's start, its finding the tickets drained and its exit (three stamps per wave: the
   // timeline of the production code); the per-phase and per-ticket stamps, which cost a scalar-memory round trip
   // each and slow short passes down noticeably, only with tune bit 26.
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         if (t >= (unsigned int)P.numTiles) {
           exhausted = true;
           if (PHASES) tExhausted = __builtin_amdgcn_s_memtime();
-          if (PHASES && P.waveLog) rtDry = __builtin_amdgcn_s_memrealtime();
+          if (PHASES && P.waveLog) { rtDry = __builtin_amdgcn_s_memrealtime(); passesAtDry = nPasses; }
         } else {
           if (P.tileOrder) {
             const int at = t < nClass2 ? 2 * P.numTiles + (int)t
@@ -1264,7 +1264,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     rec[0] = rtStart;
     rec[1] = exhausted ? rtDry : 0ull;
     rec[2] = __builtin_amdgcn_s_memrealtime();
-    rec[3] = nPasses;
+    rec[3] = (unsigned long long)nPasses | ((unsigned long long)passesAtDry << 32);
   } else if (PHASES && lane == 0) {
     if (coop) atomicAdd(&P.counters[18], __builtin_amdgcn_s_memtime() - tPooled);
     atomicAdd(&P.counters[19], nPooled);

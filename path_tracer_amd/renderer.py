@@ -144,7 +144,8 @@ class HipRenderer:
         return n.value
 
     def waveTimeline(self, pushConstants) -> np.ndarray:
-        """[waves, 4] uint64: start / tickets-drained / exit clock stamps and pass count of every wave of one frame."""
+        """[waves, 4] uint64: start / tickets-drained / exit clock stamps of every wave of one frame, and its pass
+        count (low 32 bits of the fourth word; high 32 bits: passes made when it found the tickets drained)."""
         pc = self._pc(pushConstants)
         out = np.zeros((16384, 4), dtype=np.uint64)
         n = C.c_int()
