@@ -94,7 +94,7 @@ class Runner:
             raise SystemExit("renderer initialisation failed")
         self.r.setOption(1, 0)  # PT_OPT_FLOAT_OUTPUT off: the benchmark keeps the rgba8 frame only
         self.set_frames_in_flight(frames_in_flight)
-        self.r.setScene(scene)
+        self.r.setScene(scene, honour_max_depth=True)
         self.pc = scene.push_constants()
         self.bgs, self.frames, self.tstreams = [], [], []
         self.comm = None

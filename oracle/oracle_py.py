@@ -13,7 +13,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
+# PT_ORACLE_LIB: another build of the same source (the sanitizer build of tests/test_sanitizers.py)
+_LIB_PATH = os.environ.get("PT_ORACLE_LIB") or os.path.join(_HERE, "libpt_oracle.so")
 
 
 class _PtoScene(C.Structure):

@@ -524,6 +524,8 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
       hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<false>, dim3((P.numTiles + 63) / 64), dim3(64), 0, stream, P);
     PT_HIP_CHECK(hipGetLastError());
   }
+  if (P.waveLog && (size_t)blocks * (size_t)(threads / 64) * 32 > r->dWaveLog.cap)
+    return fail(PT_ERR_STATE, "pt_wave_timeline: the launch has more waves than the log holds");
   dim3 grid(blocks), block(threads);
 #define PT_LAUNCH_K(MODE_, LDS_, POOLED_, VOLUME_)                                                                     \
   {                                                                                                                    \
@@ -668,11 +670,12 @@ int pt_gather_bands(PtRenderer *r, PtComm *c, int elem_bytes, void *dst_dev) {
   PT_HIP_CHECK(r->dGathered[slot].reserve(partBytes * (size_t)c->world));
   char *const gathered = (char *)r->dGathered[slot].p;
   void *dst = dst_dev;
+  r->assembledElem[slot] = 0; // a frame assembled into the caller's buffer leaves none here to read back
   if (!dst) {
     PT_HIP_CHECK(r->dAssembled[slot].reserve((size_t)r->height * rowBytes));
     dst = r->dAssembled[slot].p;
+    r->assembledElem[slot] = elem_bytes;
   }
-  r->assembledElem[slot] = elem_bytes;
   PT_HIP_CHECK(hipMemcpyAsync(gathered, local, (size_t)r->localRows * rowBytes, hipMemcpyDeviceToDevice, stream));
   if (c->world > 1) {
     PT_NCCL_CHECK(g_rccl.GroupStart());
@@ -689,13 +692,14 @@ int pt_gather_bands(PtRenderer *r, PtComm *c, int elem_bytes, void *dst_dev) {
   return pt_assemble_bands(r, gathered, dst, elem_bytes, bandRows, c->world, strideRows);
 }
 
-void *pt_device_assembled(PtRenderer *r) { return r ? r->dAssembled[r->lastSlot].p : nullptr; }
+void *pt_device_assembled(PtRenderer *r) { return (r && r->assembledElem[r->lastSlot]) ? r->dAssembled[r->lastSlot].p : nullptr; }
 
 int pt_readback_assembled(PtRenderer *r, void *dst, size_t dst_bytes) {
   if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_assembled: null argument");
   const int slot = r->lastSlot;
   if (!r->dAssembled[slot].p || !r->assembledElem[slot]) return fail(PT_ERR_STATE, "pt_readback_assembled: no assembled frame (pt_gather_bands on rank 0 with dst_dev = NULL makes one)");
   const size_t bytes = (size_t)r->width * r->height * (size_t)r->assembledElem[slot];
+  if (r->dAssembled[slot].cap < bytes) return fail(PT_ERR_STATE, "pt_readback_assembled: the assembled frame is smaller than the frame asked for");
   if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_assembled: destination too small");
   int rc = sync_all(r);
   if (rc != PT_OK) return rc;
@@ -1142,7 +1146,7 @@ int pt_render_static(PtRenderer *r, const PtPushConstants *pc, void *rgba8_dev, 
   if (r->accumulate) return fail(PT_ERR_STATE, "pt_render_static: not inside pt_render_samples");
   char *const base = (char *)g_staticScratchPtr[r->device];
   FrameTarget t;
-  t.stream = hip_stream ? (hipStream_t)hip_stream : r->ownStream[0];
+  t.stream = hip_stream ? (hipStream_t)hip_stream : r->stream[0]; // slot 0's stream: what pt_present waits for
   t.rgba8 = rgba8_dev;
   t.f32 = f32_dev;
   t.scratch = base;
@@ -1184,7 +1188,9 @@ int pt_render_counted(PtRenderer *r, const PtPushConstants *pc, uint64_t *counte
 
 int pt_wave_timeline(PtRenderer *r, const PtPushConstants *pc, uint64_t *out, size_t capacity_waves, int *num_waves) {
   if (!r || !pc || !out || !num_waves) return fail(PT_ERR_INVALID, "pt_wave_timeline: null argument");
-  const size_t maxWaves = (size_t)r->computeUnits * 16 * 2; // more than any launch of the frame kernel has
+  // one record per wave of the launch: at most 7 workgroups per compute unit of at most 16 waves (the tuning switches
+  // can ask for that many; production launches have 16 waves per compute unit)
+  const size_t maxWaves = (size_t)r->computeUnits * 7 * 16;
   PT_HIP_CHECK(hipSetDevice(r->device));
   int rc = sync_all(r);
   if (rc != PT_OK) return rc;

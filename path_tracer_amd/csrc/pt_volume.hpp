@@ -69,7 +69,9 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
         // (512 nbx - 64), 64 i + (i >> 3) * (512 nbx nby - 512)), so the eight cells of a sample share six terms.
         constexpr int kTri = 2; // four per trip need 96 registers instead of 53 and are no faster
         while (WIDE && t < tFar && stepCount < 500) {
-          const int rowStep = (bX << 9) - 64, sliceStep = ((bX * bY) << 9) - 512; // fit 24 bits (or the copy is linear)
+          // both fit 24 bits as unsigned factors (or the copy is linear); the multiply is the unsigned one, the signed
+          // 24-bit multiply would read a factor of 2^23 or more as negative
+          const int rowStep = (bX << 9) - 64, sliceStep = ((bX * bY) << 9) - 512;
           float tsT[kTri];
           tsT[0] = t;
 #pragma unroll
@@ -99,8 +101,8 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
               const int i1 = i0 + 1 > ri[a] - 1 ? ri[a] - 1 : i0 + 1;
               const int lin = a == 0 ? 1 : (a == 1 ? rx : rx * ry);
               const int shift = 3 * a, step = a == 0 ? 504 : (a == 1 ? rowStep : sliceStep);
-              term[0][a] = brk ? (i0 << shift) + __mul24(i0 >> 3, step) : i0 * lin;
-              term[1][a] = brk ? (i1 << shift) + __mul24(i1 >> 3, step) : i1 * lin;
+              term[0][a] = brk ? (i0 << shift) + (int)__umul24((unsigned int)(i0 >> 3), (unsigned int)step) : i0 * lin;
+              term[1][a] = brk ? (i1 << shift) + (int)__umul24((unsigned int)(i1 >> 3), (unsigned int)step) : i1 * lin;
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) cell[s][c] = (unsigned int)(term[c & 1][0] + term[(c >> 1) & 1][1] + term[c >> 2][2]);
@@ -162,14 +164,15 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       }
       // Index of the (clamped) cell (ix, iy, iz).  Bricked: ((bz * nby + by) * nbx + bx) * 512 + (iz & 7) * 64 +
       // (iy & 7) * 8 + (ix & 7) with b = i >> 3, written as the linear part ix + 8 iy + 64 iz plus what each
-      // whole brick adds along its axis; the factors fit 24 bits (the host keeps the linear layout otherwise).
+      // whole brick adds along its axis; the factors fit 24 bits as unsigned numbers (the host keeps the linear layout
+      // otherwise), so the multiplies are unsigned ones: brick coordinates and steps are never negative.
       const int brickRowStep = (nbx << 9) - 64, bricksPerSliceLess1 = nbx * nby - 1;
       auto cellIndex = [&](int ix, int iy, int iz) -> int {
         if (!bricked) return ix + iy * rx + iz * rx * ry;
         int id = ix + (iy << 3) + (iz << 6);
-        id += __mul24(ix >> 3, 504);
-        id += __mul24(iy >> 3, brickRowStep);
-        return id + (__mul24(iz >> 3, bricksPerSliceLess1) << 9);
+        id += (int)__umul24((unsigned int)(ix >> 3), 504u);
+        id += (int)__umul24((unsigned int)(iy >> 3), (unsigned int)brickRowStep);
+        return id + (int)(__umul24((unsigned int)(iz >> 3), (unsigned int)bricksPerSliceLess1) << 9);
       };
       // the same as an unsigned offset (the load then takes the base address from scalar registers), with one
       // multiplication for the slices too
@@ -177,9 +180,9 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       auto cellOffset = [&](int ix, int iy, int iz) -> unsigned int {
         if (!bricked) return (unsigned int)(ix + iy * rx + iz * rx * ry);
         int id = ix + (iy << 3) + (iz << 6);
-        id += __mul24(ix >> 3, 504);
-        id += __mul24(iy >> 3, brickRowStep);
-        id += __mul24(iz >> 3, brickSliceStep);
+        id += (int)__umul24((unsigned int)(ix >> 3), 504u);
+        id += (int)__umul24((unsigned int)(iy >> 3), (unsigned int)brickRowStep);
+        id += (int)__umul24((unsigned int)(iz >> 3), (unsigned int)brickSliceStep);
         return (unsigned int)id;
       };
       // clamp(int(p), 0, res - 1) as int(clamp(p, 0, res - 1)): the same integer for every p (the conversion

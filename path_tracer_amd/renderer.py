@@ -108,10 +108,11 @@ class HipRenderer:
         _lib.check(self._lib.pt_present(self._h))
 
     # ---- beyond the reference interface ----
-    def setScene(self, scene, honour_max_depth: bool = True) -> None:
-        """Upload a ``scenes.Scene``.  The named configurations state a bounce depth
-        (``scene.max_depth``), so by default this also switches the renderer to honouring
-        ``maxDepth``; ``honour_max_depth=False`` keeps the reference's fixed 10 bounces."""
+    def setScene(self, scene, honour_max_depth: bool = False) -> None:
+        """Upload a ``scenes.Scene``.  Like ``updateScene`` and the C default this keeps the
+        reference's fixed 10 bounces (reference shaders/raytrace.comp:603) unless
+        ``honour_max_depth=True``, which makes the scene's stated depth (``scene.max_depth``,
+        sent as ``maxDepth``) the bounce limit: the named configurations are drawn that way."""
         self.honour_max_depth = honour_max_depth
         self.updateScene(scene.spheres, scene.ellipsoids, scene.materials, scene.lights, scene.volumes, scene.voxels)
 

@@ -16,7 +16,7 @@ bad = []
 for seed in range(first, first + count):
     sc = G.random_hall_of_mirrors(seed) if seed % 10 == 0 else G.random_volume_frame(seed) if seed % 10 == 5 else G.random_scene(seed)
     r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-    r.setScene(sc); pc = sc.push_constants()
+    r.setScene(sc, honour_max_depth=True); pc = sc.push_constants()
     r.render(pc); r.present()
     g8, gf = r.readbackRGBA8(), r.readbackF32()
     cnt = r.renderCounted(pc); r.shutdown()

@@ -26,7 +26,7 @@ def _renderer(sc, options=None):
     assert r.initialize(sc.width, sc.height)
     for k, v in (options or {}).items():
         r.setOption(k, v)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     return r
 
 
@@ -177,7 +177,7 @@ def test_a_larger_resolution_later_keeps_the_uploaded_voxels(oracle):
     for resend in (True, False):
         r = HipRenderer()
         assert r.initialize(160, 90)
-        r.setScene(sc_small)
+        r.setScene(sc_small, honour_max_depth=True)
         r.render(sc_small.push_constants()); r.present()
         r.updateScene(sc_big.spheres, sc_big.ellipsoids, sc_big.materials, sc_big.lights, sc_big.volumes,
                       vox if resend else None)

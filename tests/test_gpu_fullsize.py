@@ -21,7 +21,7 @@ def _render(sc, counted=True):
 
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     # poison the frame first: a pixel the kernel skips would keep the poison
     r.render(pc)

@@ -19,7 +19,7 @@ BAND = 16
 def _plain(sc):
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     r.render(sc.push_constants())
     r.present()
     out = r.readbackRGBA8(), r.readbackF32()
@@ -37,7 +37,7 @@ def test_assembled_shares_equal_the_plain_frame(world):
     gf = torch.zeros((world, stride, sc.width, 4), dtype=torch.float32, device="cuda:0")
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     for rank in range(world):  # every rank's share in turn, straight into its place in the gather buffer
         r.setRowBands(BAND, rank, world)
@@ -64,7 +64,7 @@ def test_rccl_gather_entry_points_with_one_rank():
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
     r.setOption(6, 8)  # PT_OPT_FRAMES_IN_FLIGHT
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     comm = r.commCreate(HipRenderer.commUniqueId(), 0, 1, 0)
     r.setRowBands(BAND, 0, 1)
     pc = sc.push_constants()
@@ -102,7 +102,7 @@ def test_torch_nccl_gather_with_one_rank():
         assert r.initialize(sc.width, sc.height)
         r.setOption(1, 0)
         r.setOption(6, 2)
-        r.setScene(sc)
+        r.setScene(sc, honour_max_depth=True)
         r.setRowBands(BAND, 0, 1)
         bgs, streams, frames = [], [], []
         for slot in range(2):

@@ -95,7 +95,7 @@ def test_many_spheres_lds_and_global_object_source(oracle):
         r = HipRenderer()
         assert r.initialize(sc.width, sc.height)
         r.setOption(2, source)
-        r.setScene(sc)
+        r.setScene(sc, honour_max_depth=True)
         pc = sc.push_constants()
         r.render(pc)
         r.present()
@@ -137,7 +137,7 @@ def test_row_bands_reassemble_to_the_full_frame(oracle):
     full = None
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     r.render(pc)
     r.present()
@@ -175,7 +175,7 @@ def test_update_scene_rejects_bad_material_index():
     r = HipRenderer()
     assert r.initialize(64, 48)
     with pytest.raises(PtError):
-        r.setScene(sc)
+        r.setScene(sc, honour_max_depth=True)
     with pytest.raises(PtError):  # nothing uploaded yet
         r.render(sc.push_constants())
     r.shutdown()
@@ -216,7 +216,7 @@ def test_largest_frames_index_without_overflow(oracle):
         r = HipRenderer()
         assert r.initialize(W, H)
         r.setOption(T.OPT_FLOAT_OUTPUT, 0)
-        r.setScene(sc)
+        r.setScene(sc, honour_max_depth=True)
         r.render(sc.push_constants())
         r.present()
         g8 = r.readbackRGBA8()
@@ -229,13 +229,17 @@ def test_largest_frames_index_without_overflow(oracle):
             assert g8[r0:r0 + 5, :, 3].min() == 255  # every pixel of the rows was written
 
 
-@pytest.mark.parametrize("res", [(2048, 2048, 4), (520, 300, 700)])
+@pytest.mark.parametrize("res", [(2048, 2048, 4), (520, 300, 700), (1100, 1100, 24), (1448, 1440, 16)])
 def test_large_volumes_bricked_or_not(oracle, res):
-    """109 M voxels in 8x8x8 bricks (65 x 38 x 88 of them), and a flat 2048 x 2048 x 4 volume whose bricks per slice
-    would not fit the march's 24-bit factors, so that it stays linear: both frames bit for bit, with and without solids."""
+    """109 M voxels in 8x8x8 bricks (65 x 38 x 88 of them); a flat 2048 x 2048 x 4 volume whose bricks per slice
+    would not fit the march's 24-bit factors, so that it stays linear; and two flat volumes with 19 044 and 32 580
+    bricks per slice, whose slice step (512 bytes per brick) lies between 2^23 and 2^24: a factor the march must
+    multiply as an unsigned 24-bit number.  Frames bit for bit, with and without solids; the last two also
+    with the trilinear filter."""
     from path_tracer_amd import HipRenderer
 
     vox = np.random.default_rng(7).integers(0, 24, size=res[0] * res[1] * res[2], dtype=np.uint8)
+    wide_slices = ((res[0] + 7) // 8) * ((res[1] + 7) // 8) >= 16385
     for with_sphere in (False, True):
         sc = scenes.config4(200, 112, voxels=vox, resolution=res)
         if with_sphere:
@@ -243,16 +247,18 @@ def test_large_volumes_bricked_or_not(oracle, res):
             sc.materials = scenes._materials(mats)
             sc.spheres = scenes._stack([scenes._sphere((2.2, 1.6, 0.4), 0.5, 1)], T.GPU_SPHERE)
             sc.max_depth = 3
-        r = HipRenderer()
-        assert r.initialize(sc.width, sc.height)
-        r.setScene(sc)
-        pc = sc.push_constants()
-        r.render(pc)
-        r.present()
-        gf = r.readbackF32()
-        cnt = r.renderCounted(pc)
-        r.shutdown()
-        _, rf, rc = oracle.render(sc, nthreads=16)
-        np.testing.assert_array_equal(cnt[:NA], rc[:NA])
-        same = (gf.view(np.uint32) == rf.view(np.uint32)) | (np.isnan(gf) & np.isnan(rf))
-        assert same.all(), (res, with_sphere, float(same.all(axis=-1).mean()))
+        for filt in ((0, 1) if wide_slices else (0,)):
+            r = HipRenderer()
+            assert r.initialize(sc.width, sc.height)
+            r.setOption(T.OPT_VOLUME_FILTER, filt)
+            r.setScene(sc, honour_max_depth=True)
+            pc = sc.push_constants()
+            r.render(pc)
+            r.present()
+            gf = r.readbackF32()
+            cnt = r.renderCounted(pc)
+            r.shutdown()
+            _, rf, rc = oracle.render(sc, nthreads=16, volume_filter=filt)
+            np.testing.assert_array_equal(cnt[:NA], rc[:NA])
+            same = (gf.view(np.uint32) == rf.view(np.uint32)) | (np.isnan(gf) & np.isnan(rf))
+            assert same.all(), (res, with_sphere, filt, float(same.all(axis=-1).mean()))

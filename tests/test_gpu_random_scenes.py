@@ -82,7 +82,7 @@ def test_random_scene_matches_the_oracle(oracle, seed):
     sc = random_scene(1000 + seed)
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     r.render(pc)
     r.present()
@@ -125,7 +125,7 @@ def test_random_hall_of_mirrors_matches_the_oracle(oracle, seed):
     sc = random_hall_of_mirrors(2000 + seed)
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     r.render(pc)
     r.present()
@@ -158,7 +158,7 @@ def test_random_scene_volume_modes_match_the_oracle(oracle, seed):
     assert r.initialize(sc.width, sc.height)
     r.setOption(T.OPT_VOLUME_BRICKS, bricks)
     r.setOption(T.OPT_VOLUME_FILTER, trilinear)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     if samples > 1:
         r.renderSamples(pc, 0, samples)
@@ -216,7 +216,7 @@ def test_random_volume_frame_matches_the_oracle(oracle, seed):
     assert r.initialize(sc.width, sc.height)
     r.setOption(T.OPT_VOLUME_BRICKS, bricks)
     r.setOption(T.OPT_VOLUME_FILTER, trilinear)
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     r.render(pc)
     r.present()

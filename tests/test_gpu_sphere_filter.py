@@ -25,7 +25,7 @@ def _frame(sc, tune):
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
     r.setOption(TUNE, tune)  # read when the scene is uploaded
-    r.setScene(sc)
+    r.setScene(sc, honour_max_depth=True)
     pc = sc.push_constants()
     r.render(pc)
     r.present()

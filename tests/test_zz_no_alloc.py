@@ -13,16 +13,25 @@ def _both(sc, torch, with_float):
     r = HipRenderer()
     assert r.initialize(sc.width, sc.height)
     try:
-        r.setScene(sc)
+        r.setScene(sc, honour_max_depth=True)
         pc = sc.push_constants()
         r.render(pc)
         r.present()
         want8, wantf = r.readbackRGBA8(), r.readbackF32()
         out8 = torch.full((sc.height, sc.width, 4), 7, dtype=torch.uint8, device="cuda:0")
         outf = torch.full((sc.height, sc.width, 4), -1.0, dtype=torch.float32, device="cuda:0") if with_float else None
+        s = torch.cuda.Stream(device="cuda:0")
         torch.cuda.synchronize()
+        # nothing may be allocated by the static calls: the device's free memory does not shrink across them (this
+        # sees allocations the driver serves with new pages, i.e. anything of the size of a frame or a scratch block)
+        free_before = torch.cuda.mem_get_info(0)[0]
         r.renderStatic(pc, out8.data_ptr(), None if outf is None else outf.data_ptr())
-        r.present()  # the renderer's own stream carried the frame
+        r.present()  # a null stream means the stream of frame slot 0, which present() waits for
+        r.renderStatic(pc, out8.data_ptr(), None, s.cuda_stream)
+        s.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] >= free_before
+        r.renderStatic(pc, out8.data_ptr(), None if outf is None else outf.data_ptr())
+        r.present()
         got8 = out8.cpu().numpy()
         np.testing.assert_array_equal(got8, want8)
         if with_float:
@@ -30,7 +39,6 @@ def _both(sc, torch, with_float):
         # the renderer's own frame slots are untouched by the static call
         np.testing.assert_array_equal(r.readbackRGBA8(), want8)
         # on a caller's stream
-        s = torch.cuda.Stream(device="cuda:0")
         out8.fill_(3)
         torch.cuda.synchronize()
         r.renderStatic(pc, out8.data_ptr(), None, s.cuda_stream)
@@ -61,7 +69,7 @@ def test_static_entry_point_rejects_what_it_cannot_hold():
     r = HipRenderer()
     assert r.initialize(8192, 4096)  # 524 288 tiles > 262 144
     try:
-        r.setScene(sc)
+        r.setScene(sc, honour_max_depth=True)
         with pytest.raises(PtError, match="static scratch"):
             r.renderStatic(sc.push_constants(), 0x1000)
         with pytest.raises(PtError, match="required"):

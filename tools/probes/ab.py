@@ -8,7 +8,7 @@ sc = {'c3':scenes.config3,'c2':scenes.config2,'c4':scenes.config4}[name]()
 rs = {}
 for v in vals:
     r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-    r.setOption(1,0); r.setOption(opt,v); r.setScene(sc); rs[v]=r
+    r.setOption(1,0); r.setOption(opt,v); r.setScene(sc, honour_max_depth=True); rs[v]=r
 pc = sc.push_constants()
 ms = {v:[] for v in vals}
 for i in range(n+3):

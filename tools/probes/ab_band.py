@@ -14,7 +14,7 @@ for name, mk, n in (('c2', scenes.config2, 48), ('c3', scenes.config3, 8)):
     for world in (1, 8):
         for fif in (1, 8):
             r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-            r.setOption(1, 0); r.setOption(6, fif); r.setScene(sc)
+            r.setOption(1, 0); r.setOption(6, fif); r.setScene(sc, honour_max_depth=True)
             if world > 1: r.setRowBands(16, 0, world)
             res = []
             for rep in range(4):

@@ -15,7 +15,7 @@ for name, mk, n in (('c2', scenes.config2, 40), ('c3', scenes.config3, 4), ('c4'
     sc = mk(); pc = sc.push_constants()
     for fif in (1, 2):
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-        r.setOption(1, 0); r.setOption(6, fif); r.setScene(sc)
+        r.setOption(1, 0); r.setOption(6, fif); r.setScene(sc, honour_max_depth=True)
         res = []
         for rep in range(4):
             r.timerBegin()

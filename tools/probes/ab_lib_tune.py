@@ -12,7 +12,7 @@ for fif in (1, 2):
     rs = {}
     for t in tunes:
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-        r.setOption(1, 0); r.setOption(6, fif); r.setOption(100, t); r.setScene(sc); rs[t] = r
+        r.setOption(1, 0); r.setOption(6, fif); r.setOption(100, t); r.setScene(sc, honour_max_depth=True); rs[t] = r
     ms = {t: [] for t in tunes}
     for rep in range(5):
         for t in tunes:

@@ -8,7 +8,7 @@ for world in (1,2,4,8):
     out=[]
     for v in vals:
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-        r.setOption(1,0); r.setOption(opt,v); r.setScene(sc)
+        r.setOption(1,0); r.setOption(opt,v); r.setScene(sc, honour_max_depth=True)
         if world>1: r.setRowBands(16, 0, world)
         ms=[]
         for i in range(6):

@@ -9,7 +9,7 @@ for fif in (1, 2, 4, 8):
     out = []
     for sh in (0, 1, 2, 3, 4):  # 0: automatic
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-        r.setOption(1, 0); r.setOption(6, fif); r.setOption(100, sh << 27); r.setScene(sc)
+        r.setOption(1, 0); r.setOption(6, fif); r.setOption(100, sh << 27); r.setScene(sc, honour_max_depth=True)
         if world > 1: r.setRowBands(16, 0, world)
         res = []
         for rep in range(4):

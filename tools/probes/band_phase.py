@@ -6,7 +6,7 @@ name = sys.argv[1]; world=int(sys.argv[2])
 sc = {'c3':scenes.config3,'c2':scenes.config2,'c4':scenes.config4}[name]()
 pc = sc.push_constants()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-r.setOption(1,0); r.setScene(sc)
+r.setOption(1,0); r.setScene(sc, honour_max_depth=True)
 if world>1: r.setRowBands(16, 0, world)
 cnt = r.renderCounted(pc)
 d=dict(zip(T.COUNTER_NAMES,[int(x) for x in cnt]))

@@ -8,7 +8,7 @@ for world in (1,2,4,8):
     times=[]
     for rank in range(world):
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-        r.setOption(1,0); r.setScene(sc)
+        r.setOption(1,0); r.setScene(sc, honour_max_depth=True)
         if world>1: r.setRowBands(16, rank, world)
         ms=[]
         for i in range(5):

@@ -14,7 +14,7 @@ for world in (1, 2, 4, 8):
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
         r.setOption(1, 0); r.setOption(6, fif)
         for k, val in fixed: r.setOption(k, val)
-        r.setScene(sc)
+        r.setScene(sc, honour_max_depth=True)
         if world > 1: r.setRowBands(16, 0, world)
         res = []
         for rep in range(3):

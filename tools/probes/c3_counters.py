@@ -7,7 +7,7 @@ sc = {'c3':scenes.config3,'c2':scenes.config2}[name]()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
 import os
 if os.environ.get('TUNE'): r.setOption(100,int(os.environ['TUNE']))
-r.setOption(1,0); r.setScene(sc); pc = sc.push_constants()
+r.setOption(1,0); r.setScene(sc, honour_max_depth=True); pc = sc.push_constants()
 cnt = r.renderCounted(pc)
 print(dict(zip(T.COUNTER_NAMES,[int(x) for x in cnt])))
 ns = len(sc.spheres); groups=(ns+7)//8

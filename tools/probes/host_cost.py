@@ -8,7 +8,7 @@ pc = sc.push_constants()
 for order in (0, 1):
     for fif in (1, 8):
         r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-        r.setOption(1, 0); r.setOption(3, order); r.setOption(6, fif); r.setScene(sc)
+        r.setOption(1, 0); r.setOption(3, order); r.setOption(6, fif); r.setScene(sc, honour_max_depth=True)
         for i in range(50): r.render(pc)
         r.present()
         n = 2000

@@ -4,7 +4,7 @@ from path_tracer_amd import scenes, HipRenderer
 name=sys.argv[1]; tune=int(sys.argv[2])
 sc = {'c3':scenes.config3,'c2':scenes.config2,'c4':scenes.config4}[name]()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-r.setOption(1,0); r.setOption(100,tune|(1<<26)); r.setScene(sc); pc = sc.push_constants()
+r.setOption(1,0); r.setOption(100,tune|(1<<26)); r.setScene(sc, honour_max_depth=True); pc = sc.push_constants()
 cnt = r.renderCounted(pc)  # with the per-phase stamps
 
 tot=sum(int(cnt[i]) for i in range(13,18))

@@ -11,7 +11,7 @@ def _c4_away():  # the C4 volume with the camera moved so that no ray meets the 
 sc = {'c3': scenes.config3, 'c2': scenes.config2, 'c4': scenes.config4, 'c4away': _c4_away,
       'empty': lambda: scenes.Scene(width=1920, height=1080)}[name](); pc = sc.push_constants()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-r.setOption(1, 0); r.setOption(6, 1); r.setOption(100, tune); r.setScene(sc)
+r.setOption(1, 0); r.setOption(6, 1); r.setOption(100, tune); r.setScene(sc, honour_max_depth=True)
 for i in range(n):
     r.render(pc); r.present()
 print(name, hex(tune), r.lastLaunch())

@@ -12,7 +12,7 @@ frame = torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device='cuda:0'
 res = {}
 for with_assemble in (False, True, False, True):
     r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-    r.setOption(1, 0); r.setOption(6, 8); r.setScene(sc); r.setRowBands(16, 0, world)
+    r.setOption(1, 0); r.setOption(6, 8); r.setScene(sc, honour_max_depth=True); r.setRowBands(16, 0, world)
     ms = []
     for rep in range(4):
         r.timerBegin()

@@ -12,7 +12,7 @@ for v in vals:
     r = HipRenderer(); assert r.initialize(sc.width, sc.height)
     r.setOption(1, 0)
     for k, val in fixed: r.setOption(k, val)
-    r.setOption(opt, v); r.setScene(sc)
+    r.setOption(opt, v); r.setScene(sc, honour_max_depth=True)
     res = []
     for rep in range(4):
         r.timerBegin()

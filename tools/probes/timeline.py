@@ -6,7 +6,7 @@ from path_tracer_amd import scenes, HipRenderer
 name = sys.argv[1]; tune = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
 sc = {'c3': scenes.config3, 'c2': scenes.config2, 'c4': scenes.config4}[name](); pc = sc.push_constants()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-r.setOption(1, 0); r.setOption(6, 1); r.setOption(100, tune); r.setScene(sc)
+r.setOption(1, 0); r.setOption(6, 1); r.setOption(100, tune); r.setScene(sc, honour_max_depth=True)
 for _ in range(3): r.render(pc)
 r.present()
 for rep in range(2):

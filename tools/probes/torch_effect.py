@@ -10,7 +10,7 @@ name = sys.argv[1]
 sc = {'c3': scenes.config3, 'c2': scenes.config2, 'c4': scenes.config4}[name](); pc = sc.push_constants()
 r = HipRenderer(); assert r.initialize(sc.width, sc.height)
 if mode == 3: comm = r.commCreate(HipRenderer.commUniqueId(), 0, 1, 0)  # an RCCL communicator in the process
-r.setOption(1, 0); r.setOption(6, 8); r.setOption(100, int(sys.argv[3], 0) if len(sys.argv) > 3 else 0); r.setScene(sc); r.setRowBands(16, 0, 8)
+r.setOption(1, 0); r.setOption(6, 8); r.setOption(100, int(sys.argv[3], 0) if len(sys.argv) > 3 else 0); r.setScene(sc, honour_max_depth=True); r.setRowBands(16, 0, 8)
 ms = []
 for rep in range(4):
     r.timerBegin()

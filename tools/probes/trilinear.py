@@ -8,7 +8,7 @@ from path_tracer_amd import scenes, HipRenderer
 sc = scenes.config4(); pc = sc.push_constants()
 for filt in (0, 1):
     r = HipRenderer(); assert r.initialize(sc.width, sc.height)
-    r.setOption(1, 0); r.setOption(6, 1); r.setOption(5, filt); r.setScene(sc)
+    r.setOption(1, 0); r.setOption(6, 1); r.setOption(5, filt); r.setScene(sc, honour_max_depth=True)
     ms = []
     for rep in range(5):
         r.timerBegin()
