@@ -119,7 +119,20 @@ struct PtRenderer {
   bool sceneHuge = false; // a sphere with a non-finite or > 1e9 centre/radius: rays take the exact routine
   int numSpheres = 0, numEllipsoids = 0, numMaterials = 0, numLights = 0, numVolumes = 0;
   int numEmSpheres = 0, numEmEllipsoids = 0;
-  DevBuf dSpheres, dImage, dVoxels, dBricks; // dBricks: volume 0 re-tiled into 8x8x8 bricks
+  // The scene (image + plain sphere array) lives once on the host and once per frame slot on the device: pt_update_scene
+  // only rebuilds the host copy, and a slot's device copy is refreshed on the slot's own stream in front of the next frame
+  // drawn there (from a pinned staging block per slot), so an update between two frames does not wait for the frames
+  // in flight (the reference's loop calls updateScene every frame, src/main_vulkan.cpp:352-360).
+  std::vector<char> hostScene;               // image, then (256-byte aligned) the float4 sphere array
+  size_t sceneBytes = 0, spheresOffset = 0;
+  unsigned long long sceneVersion = 0, slotVersion[kMaxSlots] = {};
+  DevBuf dScene[kMaxSlots];
+  void *hStage[kMaxSlots] = {};              // pinned host memory, hStageCap bytes
+  size_t hStageCap[kMaxSlots] = {};
+  hipEvent_t evCopied[kMaxSlots] = {};       // recorded behind the copy out of hStage[k]
+  std::vector<PtGPUEllipsoid> ellSeen;       // ellipsoid records of the previous update and what was derived from them
+  std::vector<float> ellDerived;             // (16 floats each), reused for records that did not change
+  DevBuf dVoxels, dBricks; // dBricks: volume 0 re-tiled into 8x8x8 bricks
   int brickRes[3] = {0, 0, 0};               // resolution dBricks was built for (0: not built)
   bool volumeBricks = true;                  // PT_OPT_VOLUME_BRICKS
   int volumeFilter = 0;                      // PT_OPT_VOLUME_FILTER
@@ -297,6 +310,46 @@ struct FrameTarget {
   int *tileOrder; // room for 3 x kStaticMaxTiles entries
 };
 
+// Room for the current scene in slot's device copy and staging block.  Growing the device copy waits for the frames in
+// flight on that slot (they read it), growing the staging block for the copy out of it.
+int reserve_scene(PtRenderer *r, int slot) {
+  if (r->dScene[slot].cap < r->sceneBytes) {
+    if (r->stream[slot]) PT_HIP_CHECK(hipStreamSynchronize(r->stream[slot]));
+    PT_HIP_CHECK(r->dScene[slot].reserve(r->sceneBytes + r->sceneBytes / 2));
+    r->slotVersion[slot] = 0;
+  }
+  if (r->hStageCap[slot] < r->sceneBytes) {
+    if (r->evCopied[slot]) PT_HIP_CHECK(hipEventSynchronize(r->evCopied[slot]));
+    if (r->hStage[slot]) (void)hipHostFree(r->hStage[slot]);
+    r->hStage[slot] = nullptr;
+    r->hStageCap[slot] = 0;
+    const size_t want = std::max<size_t>(r->sceneBytes + r->sceneBytes / 2, 4096);
+    PT_HIP_CHECK(hipHostMalloc(&r->hStage[slot], want, hipHostMallocDefault));
+    r->hStageCap[slot] = want;
+  }
+  if (!r->evCopied[slot]) PT_HIP_CHECK(hipEventCreateWithFlags(&r->evCopied[slot], hipEventDisableTiming));
+  return PT_OK;
+}
+
+// The slot's device copy of the scene, brought up to date on `stream` in front of the frame about to be drawn there.
+int refresh_scene(PtRenderer *r, int slot, hipStream_t stream, bool may_allocate) {
+  if (r->slotVersion[slot] == r->sceneVersion) return PT_OK;
+  if (r->dScene[slot].cap < r->sceneBytes || r->hStageCap[slot] < r->sceneBytes || !r->evCopied[slot]) {
+    if (!may_allocate)
+      return fail(PT_ERR_STATE, "pt_render_static: the scene copy of frame slot 0 has no room for this scene (it is made when pt_update_scene runs)");
+    int rc = reserve_scene(r, slot);
+    if (rc != PT_OK) return rc;
+  }
+  // the staging block is free again once the previous copy out of it has run: that copy was queued a whole round of
+  // slots ago, so this does not wait in a steady loop
+  PT_HIP_CHECK(hipEventSynchronize(r->evCopied[slot]));
+  std::memcpy(r->hStage[slot], r->hostScene.data(), r->sceneBytes);
+  PT_HIP_CHECK(hipMemcpyAsync(r->dScene[slot].p, r->hStage[slot], r->sceneBytes, hipMemcpyHostToDevice, stream));
+  PT_HIP_CHECK(hipEventRecord(r->evCopied[slot], stream));
+  r->slotVersion[slot] = r->sceneVersion;
+  return PT_OK;
+}
+
 int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const FrameTarget *fixed = nullptr) { // mode: the kernel's MODE (0 plain, 1 counting, 2 phase cycles)
   if (!r || !pc) return fail(PT_ERR_INVALID, "pt_render: null argument");
   if (!r->sceneValid) return fail(PT_ERR_STATE, "pt_render: pt_update_scene has not been called");
@@ -366,8 +419,12 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
     P.res[0] = v.resolution_x; P.res[1] = v.resolution_y; P.res[2] = v.resolution_z;
     P.volMaterial = v.materialIndex;
   }
-  P.spheres = (const float4 *)r->dSpheres.p;
-  P.image = (const float4 *)r->dImage.p;
+  {
+    int rcScene = refresh_scene(r, slot, stream, /*may_allocate=*/!fixed);
+    if (rcScene != PT_OK) return rcScene;
+  }
+  P.spheres = (const float4 *)((const char *)r->dScene[slot].p + r->spheresOffset);
+  P.image = (const float4 *)r->dScene[slot].p;
   P.imageFloat4s = r->imageFloat4s;
   P.offRadius = r->offRadius;
   P.offEll = r->offEll;
@@ -550,14 +607,6 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   r->lastBlocks = blocks;
   r->lastThreads = threads;
   r->lastLds = (int)ldsBytes;
-  return PT_OK;
-}
-
-template <typename T>
-int upload(DevBuf &buf, const std::vector<T> &host, hipStream_t stream) {
-  if (host.empty()) return PT_OK;
-  PT_HIP_CHECK(buf.reserve(host.size() * sizeof(T)));
-  PT_HIP_CHECK(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
   return PT_OK;
 }
 
@@ -758,11 +807,13 @@ void pt_destroy(PtRenderer *r) {
   (void)hipSetDevice(r->device);
   for (int k = 0; k < r->numSlots; ++k)
     if (r->stream[k]) (void)hipStreamSynchronize(r->stream[k]);
-  DevBuf *bufs[] = {&r->dSpheres, &r->dImage, &r->dVoxels, &r->dBricks, &r->dAccum, &r->dWaveLog};
+  DevBuf *bufs[] = {&r->dVoxels, &r->dBricks, &r->dAccum, &r->dWaveLog};
   for (DevBuf *b : bufs) b->release();
   for (int k = 0; k < PtRenderer::kMaxSlots; ++k) {
     r->dRgba8[k].release(); r->dF32[k].release(); r->dScratch[k].release(); r->dTileOrder[k].release();
-    r->dGathered[k].release(); r->dAssembled[k].release();
+    r->dGathered[k].release(); r->dAssembled[k].release(); r->dScene[k].release();
+    if (r->hStage[k]) (void)hipHostFree(r->hStage[k]);
+    if (r->evCopied[k]) (void)hipEventDestroy(r->evCopied[k]);
     if (r->evCross[k]) (void)hipEventDestroy(r->evCross[k]);
     if (r->ownStream[k]) (void)hipStreamDestroy(r->ownStream[k]);
   }
@@ -798,11 +849,9 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
         (long long)v.resolution_x * v.resolution_y * v.resolution_z > 0x7fffffffll)
       return fail(PT_ERR_INVALID, "pt_update_scene: volume 0 resolution must be positive with fewer than 2^31 voxels");
   }
-  // The frames in flight may still be reading the buffers we are about to refill.
-  {
-    int rcSync = sync_all(r);
-    if (rcSync != PT_OK) return rcSync;
-  }
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  // Nothing here waits for the frames in flight unless the voxels change (below): the records go into the host copy
+  // of the scene, and every frame slot refreshes its device copy on its own stream before its next frame.
 
   // AoS records -> one scene image (see FrameParams in pt_device.hpp) + the plain sphere array.
   if (num_materials > 65536) return fail(PT_ERR_INVALID, "pt_update_scene: more than 65536 materials");
@@ -970,10 +1019,25 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     }
     return f;
   };
+  // (a caller that moves a few ellipsoids per frame pays for those only: what was derived from a record is kept
+  // and reused while the record's bytes stay the same)
+  static_assert(sizeof(EllFilter) == 16 * sizeof(float), "EllFilter is kept as 16 floats");
+  std::vector<float> derived((size_t)num_ellipsoids * 16);
+  for (int i = 0; i < num_ellipsoids; ++i) {
+    EllFilter f;
+    if ((size_t)i < r->ellSeen.size() && std::memcmp(&r->ellSeen[i], &ellipsoids[i], sizeof(PtGPUEllipsoid)) == 0)
+      std::memcpy(&f, &r->ellDerived[(size_t)i * 16], sizeof f);
+    else
+      f = ellipsoid_filter(ellipsoids[i]);
+    std::memcpy(&derived[(size_t)i * 16], &f, sizeof f);
+  }
+  r->ellSeen.assign(ellipsoids, ellipsoids + num_ellipsoids);
+  r->ellDerived.swap(derived);
+  auto filter_of = [&](int i) { EllFilter f; std::memcpy(&f, &r->ellDerived[(size_t)i * 16], sizeof f); return f; };
   const int offEllPair = (int)img.size();
   for (int p = 0; 2 * p < num_ellipsoids; ++p) {
-    const EllFilter a = ellipsoid_filter(ellipsoids[2 * p]);
-    const EllFilter b = ellipsoid_filter(ellipsoids[std::min(2 * p + 1, num_ellipsoids - 1)]);
+    const EllFilter a = filter_of(2 * p);
+    const EllFilter b = filter_of(std::min(2 * p + 1, num_ellipsoids - 1));
     img.push_back(make_float4(a.c[0], b.c[0], a.c[1], b.c[1]));
     img.push_back(make_float4(a.c[2], b.c[2], a.c1, b.c1));
     img.push_back(make_float4(a.nc2, b.nc2, a.m[0], b.m[0]));
@@ -1028,14 +1092,38 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
     if (!mi.empty()) std::memcpy(&img[offMatIdx], mi.data(), mi.size() * 2);
   }
 
-  int rc;
-  if ((rc = upload(r->dSpheres, hs, r->stream[0])) != PT_OK) return rc;
-  if ((rc = upload(r->dImage, img, r->stream[0])) != PT_OK) return rc;
+  // The host copy of the scene: the image, then the plain sphere array.
+  {
+    const size_t imageBytes = img.size() * sizeof(float4);
+    const size_t spheresOffset = (imageBytes + 255) & ~(size_t)255;
+    const size_t total = spheresOffset + std::max<size_t>(hs.size(), 1) * sizeof(float4);
+    r->hostScene.assign(total, 0);
+    if (imageBytes) std::memcpy(r->hostScene.data(), img.data(), imageBytes);
+    if (!hs.empty()) std::memcpy(r->hostScene.data() + spheresOffset, hs.data(), hs.size() * sizeof(float4));
+    r->sceneBytes = total;
+    r->spheresOffset = spheresOffset;
+    r->sceneVersion++;
+    // room in every slot that exists (so that pt_render_static, which may not allocate, finds it)
+    for (int k = 0; k < r->numSlots; ++k) {
+      int rcRoom = reserve_scene(r, k);
+      if (rcRoom != PT_OK) return rcRoom;
+    }
+  }
 
   if (num_volumes > 0) {
     r->volume0 = volumes[0];
     size_t need = (size_t)volumes[0].resolution_x * volumes[0].resolution_y * volumes[0].resolution_z;
-    if (voxels && voxel_bytes > 0 && !r->voxelsUploaded) {
+    const PtGPUVolumetricData &v = volumes[0];
+    const bool newVoxels = voxels && voxel_bytes > 0 && !r->voxelsUploaded;
+    const bool grow = !newVoxels && (!r->voxelsUploaded || r->voxelBytes < need);
+    const bool rebrick = newVoxels || grow || r->brickRes[0] != v.resolution_x || r->brickRes[1] != v.resolution_y ||
+                         r->brickRes[2] != v.resolution_z;
+    if (rebrick) {
+      // The voxel buffers change under the frames in flight: wait for them (first upload, or a new resolution).
+      int rcSync = sync_all(r);
+      if (rcSync != PT_OK) return rcSync;
+    }
+    if (newVoxels) {
       // Uploaded once (reference src/VulkanRenderer.cpp:961-987).  All of the caller's bytes are kept: the
       // reference keeps the file's bytes and indexes them with whatever resolution the current scene
       // states.  Voxels the file did not supply read as 0.
@@ -1046,7 +1134,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
       r->voxelsUploaded = true;
       r->voxelBytes = cap;
       r->brickRes[0] = 0; // rebuild the bricked copy
-    } else if (!r->voxelsUploaded || r->voxelBytes < need) {
+    } else if (grow) {
       // A volume without data marches through zeros; a volume whose resolution outgrows what was
       // uploaded keeps the uploaded bytes (re-indexed, as in the reference) and reads zeros beyond them.
       DevBuf bigger;
@@ -1060,15 +1148,12 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
       r->voxelBytes = need;
       r->brickRes[0] = 0;
     }
-  }
-  if (num_volumes > 0) {
     // Bricked copy for the march (the linear copy stays: the reference keeps the file's bytes and
     // indexes them with whatever resolution the current scene states).
-    const PtGPUVolumetricData &v = volumes[0];
     if (r->brickRes[0] != v.resolution_x || r->brickRes[1] != v.resolution_y || r->brickRes[2] != v.resolution_z) {
       const int nbx = (v.resolution_x + 7) / 8, nby = (v.resolution_y + 7) / 8, nbz = (v.resolution_z + 7) / 8;
       const long long brickBytes = (long long)nbx * nby * nbz * 512;
-      if (brickBytes <= 0x7fffffffll && (long long)nbx * nby < 32768) { // the march indexes with 32-bit integers and 24-bit factors (512 nbx nby)
+      if (brickBytes <= 0x7fffffffll && (long long)nbx * nby < 32768) { // the march indexes with 32-bit integers and unsigned 24-bit factors (512 nbx nby)
         PT_HIP_CHECK(r->dBricks.reserve((size_t)brickBytes));
         const int grid = (int)std::min<long long>((brickBytes / 4 + 255) / 256, 65536);
         hipLaunchKernelGGL(ptdev::pt_brick_volume_kernel, dim3(grid), dim3(256), 0, r->stream[0], (const uint8_t *)r->dVoxels.p,
@@ -1079,9 +1164,9 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
         r->brickRes[0] = r->brickRes[1] = r->brickRes[2] = 0;
       }
     }
+    // The caller's voxel bytes die at return and the other slots' streams must see the new volume: finish first.
+    if (rebrick) PT_HIP_CHECK(hipStreamSynchronize(r->stream[0]));
   }
-  // The host vectors die at return: finish the copies first.
-  PT_HIP_CHECK(hipStreamSynchronize(r->stream[0]));
 
   r->sceneHuge = sceneHuge;
   {

@@ -161,6 +161,76 @@ def test_frames_in_flight_show_the_latest_frame(in_flight):
     r.shutdown()
 
 
+@pytest.mark.parametrize("in_flight", [2, 3, 8])
+def test_scene_updates_between_frames_in_flight(in_flight):
+    """The reference's loop calls updateScene before every render (reference src/main_vulkan.cpp:352-374).  Here an
+    update does not wait for the frames in flight: each frame slot refreshes its own copy of the scene in front of
+    its next frame.  Every frame of a sequence queued back to back (update, render, update, render, ... with the
+    ellipsoids re-oriented, a sphere moved and the object counts changing) must be the frame its own scene gives
+    when drawn alone."""
+    torch = pytest.importorskip("torch")
+    import copy
+
+    base = scenes.config2(320, 180, n_spheres=16, n_ellipsoids=5, max_depth=4)
+    versions, pcs = [], []
+    for k in range(7):
+        s2 = copy.copy(base)
+        s2.ellipsoids = base.ellipsoids.copy()
+        s2.ellipsoids["rotation"] = scenes.axis_angle_quat((2.0, 1.0, 0.0), (k + 1) / 7.0)
+        s2.spheres = base.spheres.copy()
+        s2.spheres["center"][3] += np.float32(0.15 * k)
+        if k % 3 == 2:  # fewer objects: the scene image shrinks and its offsets move
+            s2.spheres = s2.spheres[:-3].copy()
+            s2.ellipsoids = s2.ellipsoids[:-1].copy()
+        s2.camera_pos = (5.0 - 0.3 * k, 1.5, 6.0)
+        versions.append(s2)
+        pcs.append(s2.push_constants())
+    want = []
+    for s2, pc in zip(versions, pcs):
+        solo = _renderer(s2, {T.OPT_FRAMES_IN_FLIGHT: 1})
+        want.append(_frame(solo, pc)[0].copy())
+        solo.shutdown()
+    assert not np.array_equal(want[0], want[1])
+
+    r = _renderer(versions[0], {T.OPT_FRAMES_IN_FLIGHT: in_flight, T.OPT_FLOAT_OUTPUT: 0})
+    outs = [torch.zeros((base.height, base.width, 4), dtype=torch.uint8, device="cuda:0") for _ in range(in_flight)]
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(in_flight)]
+    torch.cuda.synchronize()
+    slot = 1 % in_flight  # the first frame goes to slot 1
+    for s2, pc in zip(versions, pcs):  # the whole sequence queued back to back, no wait in between
+        r.updateScene(s2.spheres, s2.ellipsoids, s2.materials, s2.lights, s2.volumes)
+        r.render(pc)
+        assert r.lastSlot() == slot
+        slot = (slot + 1) % in_flight
+    r.present()
+    # the last `in_flight` frames are still in their slots' buffers: look at the most recent one through readback ...
+    np.testing.assert_array_equal(r.readbackRGBA8(), want[-1])
+    # ... and draw the whole sequence again, this time reading every frame back (readback waits, so nothing overlaps):
+    # the slots' scene copies must follow the updates whichever slot a frame lands in
+    for k in (3, 0, 6, 2, 5):
+        s2 = versions[k]
+        r.updateScene(s2.spheres, s2.ellipsoids, s2.materials, s2.lights, s2.volumes)
+        r.render(pcs[k])
+        np.testing.assert_array_equal(r.readbackRGBA8(), want[k])
+    # caller-owned frames per slot: queue `in_flight` updates + frames back to back and look at all of them
+    r.present()
+    for j in range(in_flight):
+        r.setSlot(j, streams[j].cuda_stream, outs[j].data_ptr(), None)
+    first = r.lastSlot()
+    order = []
+    for j in range(min(in_flight, len(versions))):
+        s2 = versions[j]
+        r.updateScene(s2.spheres, s2.ellipsoids, s2.materials, s2.lights, s2.volumes)
+        r.render(pcs[j])
+        order.append(r.lastSlot())
+    r.present()
+    torch.cuda.synchronize()
+    assert len(set(order)) == len(order), (first, order)
+    for j, sl in enumerate(order):
+        np.testing.assert_array_equal(outs[sl].cpu().numpy(), want[j])
+    r.shutdown()
+
+
 def test_a_larger_resolution_later_keeps_the_uploaded_voxels(oracle):
     """The reference uploads the voxel bytes once and indexes them with whatever resolution the current
     scene states (reference src/VulkanRenderer.cpp:961-987); a later update that states a larger
