@@ -37,10 +37,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# A split frame is drawn with eight frame slots, one stream each; HIP gives a process four hardware queues unless
-# told otherwise, and reads this when the runtime starts: set it before anything loads HIP.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-split" in sys.argv:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# A split frame is drawn with eight frame slots, one stream each, and the slots only run side by side when each stream
+# has a hardware queue of its own.  HIP gives a process four unless told otherwise, and an RCCL communicator (or torch's
+# CUDA context) in the process takes its part of them: measured on one rank's 1/8 share of the 4K / 4096-sphere frame
+# with a communicator in the process, 8 queues -> 4 streams side by side (2.72 ms per frame), 16 queues -> 8 (2.08 ms).
+# HIP reads the variable when the runtime starts: set it before anything loads HIP.  The GPU boxes export it as 4, so a
+# default would never apply: a split run raises whatever it finds below 16 (--hw-queues N overrides, 0 leaves it alone).
+def _hw_queues_wanted():
+    if "--hw-queues" in sys.argv[:-1]:
+        return int(sys.argv[sys.argv.index("--hw-queues") + 1])
+    return 16 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-split" in sys.argv) else 0
+
+
+if _hw_queues_wanted() > 0:
+    try:
+        _have = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+    except ValueError:
+        _have = 0
+    if _have < _hw_queues_wanted() or "--hw-queues" in sys.argv[:-1]:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(min(_hw_queues_wanted(), 32))
 
 import numpy as np  # noqa: E402
 
@@ -380,6 +395,9 @@ def main():
                     help="frames queued at once, each on a stream of its own (default: 2 on one GPU, as the reference's "
                          "MAX_FRAMES_IN_FLIGHT; 8 when the frame is split over several GPUs, where a rank's share is short "
                          "against its longest chain of dependent rays); 1: one at a time")
+    ap.add_argument("--hw-queues", type=int, default=None,
+                    help="GPU_MAX_HW_QUEUES for this process (read before HIP starts; default: 16 when the frame is split, "
+                         "else whatever the environment says)")
     ap.add_argument("--force-split", action="store_true",
                     help="testing: take the band-split + gather path even with one rank (exercises the RCCL plumbing on one GPU)")
     args = ap.parse_args()
@@ -480,6 +498,7 @@ def main():
         }
         result["frames_in_flight"] = fif
         result["streams_side_by_side"] = side_by_side
+        result["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
         if n_gpus == 1:
             # the headline mode itself: the algorithmic FLOP of the K timed frames over the HIP-event time of the region
             hl = roofline_for(cnt, ev_ms / args.steps)

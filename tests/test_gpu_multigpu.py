@@ -124,3 +124,33 @@ def test_torch_nccl_gather_with_one_rank():
         r.shutdown()
     finally:
         dist.destroy_process_group()
+
+
+def test_eight_slots_run_side_by_side_next_to_an_rccl_communicator():
+    """Eight frames in flight need eight hardware queues for the slots' streams, and an RCCL communicator in the process
+    takes queues of its own: with GPU_MAX_HW_QUEUES = 16 (what bench.py sets when the frame is split) the library must
+    measure 8 streams side by side although the communicator was there first.  The variable is read when HIP starts, so
+    the check runs in a process of its own."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys
+sys.path.insert(0, ".")
+from path_tracer_amd import HipRenderer, scenes
+sc = scenes.config3(960, 540, n_spheres=300, max_depth=3)
+r = HipRenderer(); assert r.initialize(sc.width, sc.height)
+comm = r.commCreate(HipRenderer.commUniqueId(), 0, 1, 0)   # before the eight slots' streams exist
+r.setOption(1, 0); r.setOption(6, 8); r.setScene(sc, honour_max_depth=True); r.setRowBands(16, 0, 1)
+pc = sc.push_constants()
+for i in range(16): r.render(pc); r.gatherBands(comm, 4)
+r.present()
+print("side_by_side", r.streamConcurrency())
+r.commDestroy(comm); r.shutdown()
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("side_by_side")]
+    assert line and int(line[0].split()[1]) == 8, out.stdout + out.stderr
