@@ -13,10 +13,11 @@
 #include <string>
 #include <vector>
 
-// Reads the "Resolution:" line of the .dat header (fields separated by spaces
-// or tabs; other lines are ignored; default 1 1 1) and then resolution.x*y*z
-// bytes of the .raw file, x fastest.  A short .raw file only warns: the missing
-// voxels are zero.  Returns false if either file cannot be opened.
+// Reads the "Resolution:" line of the .dat header and then resolution.x*y*z bytes of the .raw file, x
+// fastest.  A header line counts when it begins with "Resolution:" and three integers follow, separated by
+// spaces or tabs (what the reference's sscanf patterns accept, src/main_vulkan.cpp:42-46: the key at the very
+// start of the line, the colon right behind it); other lines are ignored and the default is 1 1 1.  A short
+// .raw file only warns: the missing voxels are zero.  Returns false if either file cannot be opened.
 inline bool loadVolumetricData(const std::string &datFile, const std::string &rawFile,
                                std::vector<uint8_t> &volumeData, glm::ivec3 &resolution) {
   std::ifstream dat(datFile);
@@ -25,14 +26,12 @@ inline bool loadVolumetricData(const std::string &datFile, const std::string &ra
     return false;
   }
   resolution = glm::ivec3(1, 1, 1);
+  static const char kKey[] = "Resolution:";
   std::string line;
   while (std::getline(dat, line)) {
-    const auto key = line.find("Resolution");
-    if (key == std::string::npos) continue;
-    const auto colon = line.find(':', key);
-    if (colon == std::string::npos) continue;
+    if (line.compare(0, sizeof kKey - 1, kKey) != 0) continue;
     int x = 0, y = 0, z = 0;
-    if (std::sscanf(line.c_str() + colon + 1, "%d %d %d", &x, &y, &z) == 3) resolution = glm::ivec3(x, y, z);
+    if (std::sscanf(line.c_str() + (sizeof kKey - 1), " %d %d %d", &x, &y, &z) == 3) resolution = glm::ivec3(x, y, z);
   }
   std::ifstream raw(rawFile, std::ios::binary);
   if (!raw.is_open()) {

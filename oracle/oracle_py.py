@@ -62,6 +62,12 @@ def lib():
         L.pto_march_volume.restype = None
         L.pto_march_volume.argtypes = [C.POINTER(_PtoScene), C.c_void_p, fp, fp, C.c_float, fp,
                                        C.POINTER(C.c_uint64)]
+        L.pto_intersect_box.restype = C.c_int
+        L.pto_intersect_box.argtypes = [fp, fp, fp, fp, fp, fp]
+        L.pto_sample_volume.restype = C.c_float
+        L.pto_sample_volume.argtypes = [C.POINTER(_PtoScene), C.c_void_p, fp, C.c_int]
+        L.pto_counter_count.restype = C.c_int
+        L.pto_counter_count.argtypes = []
         L.pto_surface_shader.restype = None
         L.pto_surface_shader.argtypes = [C.POINTER(_PtoScene), C.c_void_p, C.c_int, fp, fp, fp, C.c_int, fp]
         _lib = L
@@ -166,6 +172,20 @@ def march_volume(scene, origin, direction, max_dist=1e10):
     lib().pto_march_volume(C.byref(held.c), pc.ctypes.data, _f3(origin), _f3(direction), max_dist, out,
                            C.byref(steps))
     return np.array(out[:], np.float32), steps.value
+
+
+def intersect_box(origin, direction, box_min, box_max):
+    """intersectBox (raytrace.comp:519-532) -> (hit, tNear, tFar)."""
+    tn, tf = C.c_float(), C.c_float()
+    hit = lib().pto_intersect_box(_f3(origin), _f3(direction), _f3(box_min), _f3(box_max), C.byref(tn), C.byref(tf))
+    return bool(hit), tn.value, tf.value
+
+
+def sample_volume(scene, point, volume_filter: int = 0) -> float:
+    """sampleVolume (raytrace.comp:485-517) of volume 0 at a world position."""
+    held = _Held(scene)
+    pc = scene.push_constants()
+    return float(lib().pto_sample_volume(C.byref(held.c), pc.ctypes.data, _f3(point), volume_filter))
 
 
 def surface_shader(scene, shader_index, hit_point, normal, view_dir, material_index):

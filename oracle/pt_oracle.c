@@ -826,6 +826,20 @@ void pto_march_volume(const PtoScene *scene, const PtPushConstants *pc,
   if (steps) *steps = c.cnt[PT_CNT_VOXEL_SAMPLES];
 }
 
+int pto_intersect_box(const float origin[3], const float dir[3], const float box_min[3],
+                      const float box_max[3], float *t_near, float *t_far) {
+  Ray r = {ld3(origin), ld3(dir)};
+  return intersectBox(r, ld3(box_min), ld3(box_max), t_near, t_far);
+}
+
+float pto_sample_volume(const PtoScene *scene, const PtPushConstants *pc, const float point[3],
+                        int volume_filter) {
+  Ctx c;
+  memset(&c, 0, sizeof c);
+  c.s = scene; c.pc = pc; c.volume_filter = volume_filter;
+  return sampleVolume(&c, ld3(point), 0);
+}
+
 void pto_surface_shader(const PtoScene *scene, const PtPushConstants *pc, int shader_index,
                         const float hit_point[3], const float normal[3],
                         const float view_dir[3], int material_index, float out[3]) {

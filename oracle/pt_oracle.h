@@ -87,6 +87,14 @@ void pto_march_volume(const PtoScene *scene, const PtPushConstants *pc,
                       const float origin[3], const float dir[3],
                       float max_dist, float out[3], uint64_t *steps);
 
+/* intersectBox: returns 1 when the ray meets the box and fills *t_near, *t_far. */
+int pto_intersect_box(const float origin[3], const float dir[3], const float box_min[3],
+                      const float box_max[3], float *t_near, float *t_far);
+
+/* sampleVolume on volume 0 at a world position (volume_filter 0: nearest, as the shader). */
+float pto_sample_volume(const PtoScene *scene, const PtPushConstants *pc, const float point[3],
+                        int volume_filter);
+
 /* surfaceShader_Rainbow / surfaceShader_Toon probes: index 1 / 2.
  * Returns color+emissive (what calculateLighting returns for the shader). */
 void pto_surface_shader(const PtoScene *scene, const PtPushConstants *pc,
