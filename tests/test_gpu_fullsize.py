@@ -103,6 +103,36 @@ def test_c5_full_size_sampled_rows(oracle):
     assert c["voxel_samples"] > 10_000_000 and c["ellipsoid_roots"] > 0
 
 
+def test_c5_full_config_64_samples_sampled_rows(oracle):
+    """The fifth configuration as stated: 4K, C2's objects and the volume, 64 samples per pixel accumulated on the
+    device (one launch per sample, running sum in a float4 frame, mean of the clamped samples).  Eight rows spread
+    over the frame against the oracle's mean of the same 64 samples per pixel."""
+    from path_tracer_amd import HipRenderer
+
+    sc = scenes.config5()
+    spp = 64
+    r = HipRenderer()
+    assert r.initialize(sc.width, sc.height)
+    r.setScene(sc, honour_max_depth=True)
+    pc = sc.push_constants()
+    r.renderSamples(pc, 0, spp)
+    r.present()
+    g8, gf = r.readbackRGBA8(), r.readbackF32()
+    r.shutdown()
+    assert (g8[..., 3] == 255).all()
+    rows = [37, 411, 838, 1080, 1302, 1577, 1893, 2159]
+    checked = ok8 = okf = 0
+    for y in rows:
+        r8, rf, _ = oracle.render(sc, rows=(y, y + 1), nthreads=16, num_samples=spp)
+        d8 = np.abs(g8[y].astype(np.int16) - r8[y].astype(np.int16)).max(axis=-1)
+        err = np.abs(gf[y] - rf[y])
+        ok8 += int((d8 <= 1).sum())
+        okf += int((err <= 1e-4 * np.maximum(np.abs(rf[y]), 1e-2)).all(axis=-1).sum())
+        checked += sc.width
+    print(f"[c5 4K x{spp} spp] {len(rows)} rows, {checked} px: rgba8<=1LSB {ok8 / checked:.6f} float<=1e-4 {okf / checked:.6f}")
+    assert ok8 / checked >= 0.999 and okf / checked >= 0.999
+
+
 def test_demo_scene_1080p_sampled_rows(oracle):
     """The reference's demo scene (src/main_vulkan.cpp:136-223) at orbit frame 40, 1080p, ten bounces, rainbow shader
     at time 1234 ms, walnut volume."""
