@@ -294,10 +294,17 @@ def roofline_for(cnt, kernel_ms: float, traffic=None, cache=None):
 
 
 def cpu_baseline(scene, budget_s: float = 20.0):
-    """The oracle on this host, all cores up to 16, on a row-subsampled frame sized for ~budget_s."""
+    """The oracle on this host's cores, on a row-subsampled frame sized for ~budget_s.  A one-GPU box is a slice of a
+    larger machine: os.cpu_count() shows the whole machine, the slice's share is what OMP_NUM_THREADS states (16 on
+    the GPU boxes), and the oracle uses that many threads (all cores where no share is stated)."""
     from oracle import oracle_py
 
-    threads = min(os.cpu_count() or 1, 16)
+    host_cpus = os.cpu_count() or 1
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    threads = min(host_cpus, share) if share > 0 else host_cpus
     # probe 1/16 of the rows to size the sample
     H = scene.height
     probe_rows = max(H // 16, 1)
@@ -314,7 +321,8 @@ def cpu_baseline(scene, budget_s: float = 20.0):
     else:
         sample = f"rows {y0}..{y0 + probe_rows} of {H} ({scene.width} px wide), 1 pass"
     return {"value": round(float(cnt[0]) / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": sample, "seconds": round(dt, 3),
+            "sample": sample, "seconds": round(dt, 3), "host_cpu_count": host_cpus,
+            "cpu_share": share if share > 0 else None,
             "note": "CPU oracle: float32 restatement of the reference shader (the reference has no CPU renderer)"}
 
 

@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   unsigned int cRoots = 0, cERoots = 0; // lane-level root evaluations (discriminant >= 0)
   unsigned int cGroups = 0, cSlow = 0;  // wave-level: 8-sphere trips, trips with at least one root
   unsigned int cExact = 0;              // rays this lane sent to the exact routine
+  unsigned int cTests = 0, cETests = 0; // (ray, sphere) and (ray, ellipsoid) pairs this lane put through a test, counted where the test runs
   unsigned long long tPooled = 0, nPooled = 0, nPooledRays = 0;
   unsigned long long cycRefill = 0, cycSpheres = 0, cycExact = 0, cycEll = 0, cycShade = 0, tPhase = 0; // wave-level s_memtime sums
   unsigned long long cycTicket = 0, nTickets = 0, tExhausted = 0, tStart = 0;
@@ -470,6 +471,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             m = __builtin_fmaxf(__builtin_fmaxf(m, d2.y), d3.x);
             m = __builtin_fmaxf(m, d3.y);
             if (COUNT) cGroups++;
+            if (COUNT && has) cTests += (unsigned int)(Ns - 8 * g < 8 ? Ns - 8 * g : 8); // the padding copies are no spheres
             if (ballot64(m >= thr) != 0ull) {
               if (COUNT) cSlow++;
               PT_ENQUEUE(8 * g, d0.x)
@@ -555,6 +557,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             const float v = (t0 < tMin) ? t1 : t0;
             if (root && !(v < tMin) && v <= myBest) { myBest = v; myIdx = base + 64 * u + lane; }
             if (COUNT) roots += root ? 1u : 0u;
+            if (COUNT && in4[u]) cTests++;
           }
         }
         unsigned long long key = ((unsigned long long)__float_as_uint(myBest) << 32) |
@@ -705,6 +708,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
             bool valid = root && !nanacc;
             if (t0 < tMin) { v = t1; valid = valid && !(t1 < tMin); }
             if (COUNT) roots += (unsigned int)__popcll(ballot64(root));
+            if (COUNT && inb) cTests++;
             const unsigned long long nm = ballot64(nanacc);
             if (nm != 0ull) {
               const int kl = 63 - (int)__builtin_clzll(nm);
@@ -795,6 +799,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           const f2 inner = fma2(xx, mk2(g1.z, g1.w), mk2(g2.x, g2.y));
           const f2 V = fma2(xd, xd, -(DD * inner));
           const unsigned long long nearMask = ballot64(__builtin_fmaxf(V.x, V.y) >= 0.0f) & qMask;
+          if (COUNT && qLane) cETests += 2 * p + 1 < Ne ? 2u : 1u; // an odd count's last pair holds one ellipsoid twice
           if (nearMask == 0ull) continue;
           // Stage 2, the quadratic through the matrix, for the pairs some ray of the wave comes near.
           const float4 g3 = PT_ELLP(p, 3), g4 = PT_ELLP(p, 4), g5 = PT_ELLP(p, 5), g6 = PT_ELLP(p, 6), g7 = PT_ELLP(p, 7);
@@ -856,6 +861,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         const float hb = dot3(ocS, dS);
         const float c = dot3(ocS, ocS) - 1.0f;
         const float disc = __builtin_fmaf(hb, hb, -(a * c));
+        if (COUNT) cETests++;
         if (ballot64(!(disc < 0.0f)) != 0ull) {
           if (!(disc < 0.0f)) {
             if (COUNT) cERoots++;
@@ -1284,8 +1290,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
     // wave reduction, then one atomic per counter per wave
     unsigned long long v[13];
     v[0] = cRays; v[1] = cPath; v[2] = cLight; v[3] = cEmis;
-    v[4] = (unsigned long long)cRays * (unsigned long long)(Ns > 0 ? Ns : 0);
-    v[5] = (unsigned long long)cRays * (unsigned long long)(Ne > 0 ? Ne : 0);
+    v[4] = cTests;  // counted where the tests run: the dense loop's trips, the exact routine's chunks
+    v[5] = cETests; // the candidate loop's pairs, the sequential loop
     v[6] = cVoxel; v[7] = cShaded; v[8] = cRoots; v[9] = cERoots;
     // wave-level counts: every live lane of a wave saw the same trips, so take lane-max, not the sum
     v[10] = 0; v[11] = 0; v[12] = cExact;
