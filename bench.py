@@ -274,13 +274,13 @@ def roofline_for(cnt, kernel_ms: float, traffic=None, cache=None):
                 "note": "17 flop per sphere test + 91 per ellipsoid test, brute force (rays x objects); "
                         "shading, sqrt/pow and hit-path work not counted"}
     achieved = vox_bytes / (kernel_ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {"bound": "valu_issue", "priced_against": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "pt_volume_frame_kernel",
            "kernel_ms": round(kernel_ms, 4), "bytes_per_launch": float(vox_bytes),
-           "note": "algorithmic bytes: 4 per nearest-neighbour voxel sample, priced against HBM as the contract asks; "
-                   "what HBM really delivers per frame is in hbm_GBs (FETCH_SIZE x 2 + WRITE_SIZE: the 41.7 MB volume about "
-                   "twice, once per group of L2s, plus the frame), what the L1s ask of the L2 in l2_requested_GBs; the kernel "
-                   "is bound by vector-instruction issue (SQ counters in profiles/), not by any memory level"}
+           "note": "achieved / peak / frac price the algorithmic bytes (4 per nearest-neighbour voxel sample) against the 8 TB/s of "
+                   "HBM, as the contract asks; what bounds the kernel is vector-instruction issue (about 25 instructions per "
+                   "sample-wave, SQ counters in profiles/), not a memory level: HBM delivers hbm_GBs (FETCH_SIZE x 2 + WRITE_SIZE: "
+                   "the 41.7 MB volume about twice, once per group of L2s, plus the frame), the L1s ask the L2 for l2_requested_GBs"}
     if traffic is not None:
         out["hbm_GBs"] = round(traffic / (kernel_ms * 1e-3) / 1e9, 1)
     if cache:

@@ -209,15 +209,20 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       // The march has no data-dependent exit, so four steps are taken per
       // trip: their voxel loads are in flight together and the accumulation
       // then runs in step order, exactly as one step per trip would.
-      constexpr int kTrip = WIDE ? 8 : 4; // samples per trip while every lane is inside the box
+      constexpr int kTrip = WIDE ? 8 : 4; // samples per trip inside the lane's safe stretch
       while (t < tFar && stepCount < 500) {
-        float ts[kTrip];
-        ts[0] = t;
+        // Trips of kTrip samples without tests, masks or per-sample validity, for as long as this lane has kTrip
+        // samples inside its safe stretch (ts[kTrip - 1] <= tSafeB < tFar: all are taken).  The lanes of a wave
+        // enter and leave their stretches at different steps; a lane that cannot take such a trip sits this loop
+        // out (it costs the others nothing) and takes its few samples at the two ends of its chord in the tested
+        // trips below, so a tile needs about (longest chord / kTrip) of these trips plus a handful of the others,
+        // whatever the spread of its chords.  ((a * rcpE) * res = a * (rcpE * res), both scalings exact.)
+        for (;;) {
+          float ts[kTrip];
+          ts[0] = t;
 #pragma unroll
-        for (int u = 1; u < kTrip; ++u) ts[u] = ts[u - 1] + 0.02f;
-        if (ballot64(!(ts[0] >= tSafeA && ts[kTrip - 1] <= tSafeB && stepCount <= 500 - kTrip)) == 0ull) {
-          // every marching lane of the wave has kTrip samples inside the box: no tests, no masks
-          // (ts[kTrip - 1] <= tSafeB < tFar: all are taken; (a * rcpE) * res = a * (rcpE * res), both scalings exact)
+          for (int u = 1; u < kTrip; ++u) ts[u] = ts[u - 1] + 0.02f;
+          if (!(ts[0] >= tSafeA && ts[kTrip - 1] <= tSafeB && stepCount <= 500 - kTrip)) break;
           unsigned int raw[kTrip];
           if (WIDE) {
 #pragma unroll
@@ -245,8 +250,12 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
           for (int u = 0; u < kTrip; ++u) acc = __builtin_fmaf(1.0f - acc, s_div255[raw[u]] * absorptionCoeff, acc);
           t = ts[kTrip - 1] + 0.02f;
           stepCount += kTrip;
-          continue;
         }
+        if (!(t < tFar && stepCount < 500)) break;
+        float ts[4];
+        ts[0] = t;
+#pragma unroll
+        for (int u = 1; u < 4; ++u) ts[u] = ts[u - 1] + 0.02f;
         int index[4];
         int n = 1;
 #pragma unroll
