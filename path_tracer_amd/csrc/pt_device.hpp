@@ -166,6 +166,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   // occlusion rays that follow its current one to idle lanes of the wave, one record each in LDS.
   int nRec = 0;              // records of this lane waiting for their results (one per round it took part in)
   int jobPos = 0;            // ST_JOB: the record this lane traces
+  // A lane whose lighting rays are all with helpers casts its next path ray in the same pass (the bounce does not
+  // depend on how the lighting ends): what calculateLighting's sum is still owed to finalColor is kept here and
+  // added, with the operands the shader would use, once the helpers have reported (before the new hit is looked at).
+  bool owedLit = false;      // finalColor += (lit * owedThr) * owedFactor is still to come
+  float owedThr = 0.0f, owedFactor = 0.0f;
   float *const f_rec = (float *)(coopBase + (size_t)waveInBlock * kFanBytes); // 13 fields x 64 records, field-major
   unsigned long long *const f_roundMask = (unsigned long long *)(f_rec + 13 * 64); // owners that took part in round r
   int *const f_roundBase = (int *)(f_roundMask + kFanRounds);                      // first record of round r
@@ -1064,6 +1069,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
                     f_rec[5 * 64 + pos], pend);
       }
       nRec = 0;
+      if (owedLit) { // raytrace.comp:651 / :663, with the throughput and the factor of the hit the sum belongs to
+        fin = add3(fin, scale3(scale3(lit, owedThr), owedFactor));
+        owedLit = false;
+      }
       if (state == ST_PATH) {
         step = GO_PATH_RESULT;
       } else if (state == ST_WAIT) {
@@ -1243,6 +1252,41 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
               gen = false;
               state = ST_WAIT;
             }
+          }
+        }
+        // A lane that has handed out every lighting ray of its hit would sit out the next pass.  Where the path goes on
+        // does not depend on the lighting (raytrace.comp:645-671: reflectivity, transparency, the normal), so it casts
+        // the next path ray now and settles finalColor next pass, first the lighting sum of this hit, then the new hit.
+        if (state == ST_WAIT && !(P.tune & (1 << 30))) {
+          const float4 m1 = PT_MAT(hitMat, 1);
+          const float4 m2 = PT_MAT(hitMat, 2);
+          const float transparency = m2.x;
+          const float reflectivity = m1.w;
+          bool cont = false;
+          float factor = 0.0f, nextThr = thr;
+          V3 nextO = hitP, nextD = curD;
+          if (reflectivity > 0.01f) {
+            factor = (1.0f - reflectivity) * (1.0f - transparency);
+            nextThr = thr * reflectivity;
+            const float kk = 2.0f * dot3(hitN, curD);
+            nextD = sub3(curD, scale3(hitN, kk));
+            nextO = madd3(hitP, kEpsilon, hitN);
+            cont = true;
+          } else if (transparency > 0.01f) {
+            factor = 1.0f - transparency;
+            nextThr = thr * transparency;
+            nextO = madd3(hitP, kEpsilon, curD);
+            cont = true;
+          }
+          // only if the loop head of traceIterative (:605-606) lets the next bounce run
+          if (cont && bounce + 1 < L.maxBounces && !(length3(mk3(nextThr, nextThr, nextThr)) < 0.001f)) {
+            owedLit = true; owedThr = thr; owedFactor = factor;
+            thr = nextThr;
+            curD = nextD;
+            bounce++;
+            rO = nextO; rD = curD; rTmax = kMaxDistance;
+            state = ST_PATH;
+            if (COUNT) cPath++;
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
