@@ -460,7 +460,12 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
       P.accumCount = r->accumCount + 1;
     }
     const int blocks = (P.numTiles + 3) / 4;
-    hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel, dim3(blocks), dim3(256), 0, stream, P);
+    // the common case (nearest-neighbour samples of a bricked volume whose extents are powers of two and whose box
+    // starts at v0 = 0) has a variant compiled for it alone
+    const bool fastVolume = P.volumeFilter == 0 && P.brickX > 0 && P.exactExtent != 0 && P.v0[0] == 0.0f && P.v0[1] == 0.0f &&
+                            P.v0[2] == 0.0f;
+    if (fastVolume) hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<true>, dim3(blocks), dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<false>, dim3(blocks), dim3(256), 0, stream, P);
     PT_HIP_CHECK(hipGetLastError());
     if (!fixed) r->lastSlot = slot;
     r->lastBlocks = blocks;

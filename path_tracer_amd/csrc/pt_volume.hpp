@@ -21,7 +21,10 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 // and the number of samples taken.
 // WIDE: trips of eight samples, two per packed operation, where every lane is inside the box (for a kernel with
 // registers to spare; the general kernel takes four, one at a time).
-template <bool WIDE, class MaterialRow>
+// FAST: the caller has checked that the volume is the common case -- nearest-neighbour filter, bricked copy, every
+// extent a power of two, v0 = (0,0,0) (the reference's volume: box (0,0,0)-(2,2,2)) -- so the code for the other
+// cases, and the wave-uniform branches that choose between them per sample, are not compiled in (x - 0 is x).
+template <bool WIDE, bool FAST, class MaterialRow>
 __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FrameParams &L, const float *s_div255, MaterialRow &&materialRow4,
                                            const V3 rO, const V3 curD, const float maxDist, unsigned int &steps) {
   float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
@@ -44,15 +47,15 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       float t = tNear;
       float acc = 0.0f;
       int stepCount = 0;
-      const V3 vpos = ld3(L.volPos), lo = ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
+      const V3 vpos = ld3(L.volPos), lo = FAST ? mk3(0.0f, 0.0f, 0.0f) : ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
       const float rcpEx = L.rcpExtent[0], rcpEy = L.rcpExtent[1], rcpEz = L.rcpExtent[2];
       const float cellTolX = 1.5f * 0x1p-22f * (float)L.res[0], cellTolY = 1.5f * 0x1p-22f * (float)L.res[1],
                   cellTolZ = 1.5f * 0x1p-22f * (float)L.res[2];
       const uint8_t *__restrict__ vox = P.voxels;
-      const bool exactExtent = L.exactExtent != 0;
-      const bool bricked = P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
+      const bool exactExtent = FAST || L.exactExtent != 0;
+      const bool bricked = FAST || P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
       const int nbx = P.brickX, nby = P.brickY;
-      if (L.volumeFilter == 1) {
+      if (!FAST && L.volumeFilter == 1) {
         // Trilinear extension: voxel centres at (i + 0.5) / res; lerp(a, b, t) =
         // fma(t, b - a, a) along x, then y, then z on the byte values, then / 255.
         const bool brk = P.brickX > 0;
@@ -194,7 +197,7 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       // rounding error is below 3e-7 of them), hence so does everything between them.  The stretch leaves out
       // the first and the last hundredth of the chord, where the entry and exit faces are closer than that.
       float tSafeA = kMaxDistance, tSafeB = -kMaxDistance;
-      if (exactExtent && L.volumeFilter != 1) {
+      if (exactExtent && (FAST || L.volumeFilter != 1)) {
         const float ta = tNear + 0.01f, tb = tFar - 0.01f;
         const V3 pa = sub3(madd3(rO, ta, curD), vpos), pb = sub3(madd3(rO, tb, curD), vpos);
         const float mx = 1e-5f * (__builtin_fabsf(rO.x) + __builtin_fabsf(vpos.x) + __builtin_fabsf(lo.x) + __builtin_fabsf(hi.x) + tFar * __builtin_fabsf(curD.x));
@@ -206,6 +209,26 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
         if (ta <= tb && inside) { tSafeA = ta; tSafeB = tb; }
       }
       const float scaleX = rcpEx * rxf, scaleY = rcpEy * ryf, scaleZ = rcpEz * rzf; // exact where the extents are powers of two
+      // A sample inside a lane's safe stretch lies inside every slab by 0.9e-5 of the magnitudes involved, so its scaled
+      // position p satisfies 0 < p < res on every axis and int(p) is a cell as it stands: clamp(int(p), 0, res - 1)
+      // of the shader changes nothing there.  One unsigned bound on the finished offset stands in for the three clamps
+      // (it never binds; it keeps a load inside the volume whatever happens).
+      const unsigned int lastByte = bricked ? (unsigned int)(nbx * nby * ((rz + 7) >> 3)) * 512u - 1u : (unsigned int)(rx * ry * rz) - 1u;
+      auto safeOffset = [&](int ix, int iy, int iz) -> unsigned int {
+        const unsigned int o = cellOffset(ix, iy, iz);
+        return o < lastByte ? o : lastByte;
+      };
+      // two samples of a safe stretch, one packed operation for both (sampleVolume's arithmetic, :485-517)
+      auto safePair = [&](const float ta, const float tb, unsigned int &ra, unsigned int &rb) {
+        const f2 tt = mk2(ta, tb);
+        f2 qx = fma2(tt, mk2(curD.x, curD.x), mk2(rO.x, rO.x)) - mk2(vpos.x, vpos.x);
+        f2 qy = fma2(tt, mk2(curD.y, curD.y), mk2(rO.y, rO.y)) - mk2(vpos.y, vpos.y);
+        f2 qz = fma2(tt, mk2(curD.z, curD.z), mk2(rO.z, rO.z)) - mk2(vpos.z, vpos.z);
+        if (!FAST) { qx = qx - mk2(lo.x, lo.x); qy = qy - mk2(lo.y, lo.y); qz = qz - mk2(lo.z, lo.z); }
+        qx = qx * mk2(scaleX, scaleX); qy = qy * mk2(scaleY, scaleY); qz = qz * mk2(scaleZ, scaleZ);
+        ra = (unsigned int)vox[safeOffset((int)qx.x, (int)qy.x, (int)qz.x)];
+        rb = (unsigned int)vox[safeOffset((int)qx.y, (int)qy.y, (int)qz.y)];
+      };
       // The march has no data-dependent exit, so four steps are taken per
       // trip: their voxel loads are in flight together and the accumulation
       // then runs in step order, exactly as one step per trip would.
@@ -226,30 +249,29 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
           unsigned int raw[kTrip];
           if (WIDE) {
 #pragma unroll
-            for (int u = 0; u < kTrip; u += 2) { // two samples per packed operation
-              const f2 tt = mk2(ts[u], ts[u + 1]);
-              const f2 qx = ((fma2(tt, mk2(curD.x, curD.x), mk2(rO.x, rO.x)) - mk2(vpos.x, vpos.x)) - mk2(lo.x, lo.x)) * mk2(scaleX, scaleX);
-              const f2 qy = ((fma2(tt, mk2(curD.y, curD.y), mk2(rO.y, rO.y)) - mk2(vpos.y, vpos.y)) - mk2(lo.y, lo.y)) * mk2(scaleY, scaleY);
-              const f2 qz = ((fma2(tt, mk2(curD.z, curD.z), mk2(rO.z, rO.z)) - mk2(vpos.z, vpos.z)) - mk2(lo.z, lo.z)) * mk2(scaleZ, scaleZ);
-              raw[u] = (unsigned int)vox[cellOffset((int)__builtin_amdgcn_fmed3f(qx.x, 0.0f, topX), (int)__builtin_amdgcn_fmed3f(qy.x, 0.0f, topY),
-                                                   (int)__builtin_amdgcn_fmed3f(qz.x, 0.0f, topZ))];
-              raw[u + 1] = (unsigned int)vox[cellOffset((int)__builtin_amdgcn_fmed3f(qx.y, 0.0f, topX), (int)__builtin_amdgcn_fmed3f(qy.y, 0.0f, topY),
-                                                       (int)__builtin_amdgcn_fmed3f(qz.y, 0.0f, topZ))];
-            }
+            for (int u = 0; u < kTrip; u += 2) safePair(ts[u], ts[u + 1], raw[u], raw[u + 1]); // two samples per packed operation
           } else {
 #pragma unroll
             for (int u = 0; u < kTrip; ++u) {
               const V3 rel = sub3(madd3(rO, ts[u], curD), vpos);
-              const int ix = (int)__builtin_amdgcn_fmed3f((rel.x - lo.x) * scaleX, 0.0f, topX);
-              const int iy = (int)__builtin_amdgcn_fmed3f((rel.y - lo.y) * scaleY, 0.0f, topY);
-              const int iz = (int)__builtin_amdgcn_fmed3f((rel.z - lo.z) * scaleZ, 0.0f, topZ);
-              raw[u] = (unsigned int)vox[cellIndex(ix, iy, iz)];
+              raw[u] = (unsigned int)vox[safeOffset((int)((rel.x - lo.x) * scaleX), (int)((rel.y - lo.y) * scaleY), (int)((rel.z - lo.z) * scaleZ))];
             }
           }
 #pragma unroll
           for (int u = 0; u < kTrip; ++u) acc = __builtin_fmaf(1.0f - acc, s_div255[raw[u]] * absorptionCoeff, acc);
           t = ts[kTrip - 1] + 0.02f;
           stepCount += kTrip;
+        }
+        // what is left of a lane's safe stretch when it is shorter than a trip: two samples at a time, still without tests
+        if (WIDE) for (;;) {
+          const float tb = t + 0.02f;
+          if (!(t >= tSafeA && tb <= tSafeB && stepCount <= 498)) break;
+          unsigned int ra, rb;
+          safePair(t, tb, ra, rb);
+          acc = __builtin_fmaf(1.0f - acc, s_div255[ra] * absorptionCoeff, acc);
+          acc = __builtin_fmaf(1.0f - acc, s_div255[rb] * absorptionCoeff, acc);
+          t = tb + 0.02f;
+          stepCount += 2;
         }
         if (!(t < tFar && stepCount < 500)) break;
         float ts[4];
@@ -258,9 +280,14 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
         for (int u = 1; u < 4; ++u) ts[u] = ts[u - 1] + 0.02f;
         int index[4];
         int n = 1;
+        // A tested trip ends early at a sample from which the lane can take trips without tests (the first sample of a
+        // chord is the only one before its safe stretch): such a sample and the ones after it are not taken here.
+        // (0.145: seven steps of 0.02 and what their rounding can add; a lane this misses just stays with the tests.)
 #pragma unroll
         for (int u = 1; u < 4; ++u)
-          if (n == u && ts[u] < tFar && stepCount + u < 500) n = u + 1;
+          if (n == u && ts[u] < tFar && stepCount + u < 500 &&
+              !(WIDE && ts[u] >= tSafeA && ts[u] + 0.145f <= tSafeB && stepCount + u <= 500 - kTrip))
+            n = u + 1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           // sampleVolume (:485-517), nearest neighbour
@@ -335,6 +362,8 @@ __device__ __forceinline__ void write_pixel(const FrameParams &P, const int accu
 // 672-679).  One wave per 8x8 tile, four tiles per workgroup, no state machine and no tickets: the kernel needs a
 // third of the general kernel's registers, so twice as many waves are resident to cover the latency of the voxel
 // loads, which is what bounds the march there.
+// FAST: see march_volume; the host launches that variant where the volume qualifies.
+template <bool FAST>
 __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams P) {
   __shared__ float s_div255[256];
   s_div255[threadIdx.x] = (float)threadIdx.x / 255.0f; // the workgroup has 256 threads
@@ -347,7 +376,7 @@ __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams 
   V3 fin = mk3(0, 0, 0);
   float thr = 1.0f;
   unsigned int steps;
-  const V3 vol = march_volume<true>(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
+  const V3 vol = march_volume<true, FAST>(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
                               kMaxDistance, steps);
   float volumeAlpha = 0.0f;
   if (vol.x >= 0.0f) volumeAlpha = glclamp(length3(vol) / length3(mk3(1.0f, 1.0f, 1.0f)), 0.0f, 1.0f); // :618-620
