@@ -182,11 +182,15 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       const int brickSliceStep = ((nbx * nby) << 9) - 512;
       auto cellOffset = [&](int ix, int iy, int iz) -> unsigned int {
         if (!bricked) return (unsigned int)(ix + iy * rx + iz * rx * ry);
-        int id = ix + (iy << 3) + (iz << 6);
-        id += (int)__umul24((unsigned int)(ix >> 3), 504u);
-        id += (int)__umul24((unsigned int)(iy >> 3), (unsigned int)brickRowStep);
-        id += (int)__umul24((unsigned int)(iz >> 3), (unsigned int)brickSliceStep);
-        return (unsigned int)id;
+        // three 24-bit multiply-adds in a chain and two shift-adds, eight instructions with the three shifts (left to
+        // itself the compiler multiplies, shifts and sums with three-input adds: ten)
+        unsigned int id;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(id) : "v"(ix >> 3), "s"(504), "v"(ix));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(id) : "v"(iy >> 3), "s"(brickRowStep), "v"(id));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(id) : "v"(iz >> 3), "s"(brickSliceStep), "v"(id));
+        asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(id) : "v"(iy), "v"(id));
+        asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(id) : "v"(iz), "v"(id));
+        return id;
       };
       // clamp(int(p), 0, res - 1) as int(clamp(p, 0, res - 1)): the same integer for every p (the conversion
       // truncates towards zero and saturates; res - 1 is a float exactly)
