@@ -460,12 +460,12 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
       P.accumCount = r->accumCount + 1;
     }
     const int blocks = (P.numTiles + 3) / 4;
-    // the common case (nearest-neighbour samples of a bricked volume whose extents are powers of two and whose box
-    // starts at v0 = 0) has a variant compiled for it alone
-    const bool fastVolume = P.volumeFilter == 0 && P.brickX > 0 && P.exactExtent != 0 && P.v0[0] == 0.0f && P.v0[1] == 0.0f &&
-                            P.v0[2] == 0.0f;
-    if (fastVolume) hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<true>, dim3(blocks), dim3(256), 0, stream, P);
-    else hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<false>, dim3(blocks), dim3(256), 0, stream, P);
+    // the common volume (bricked copy, extents that are powers of two, box starting at v0 = 0) has variants compiled
+    // for it alone, one per filter
+    const bool commonVolume = P.brickX > 0 && P.exactExtent != 0 && P.v0[0] == 0.0f && P.v0[1] == 0.0f && P.v0[2] == 0.0f;
+    if (commonVolume && P.volumeFilter == 0) hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<1>, dim3(blocks), dim3(256), 0, stream, P);
+    else if (commonVolume && P.volumeFilter == 1) hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<2>, dim3(blocks), dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<0>, dim3(blocks), dim3(256), 0, stream, P);
     PT_HIP_CHECK(hipGetLastError());
     if (!fixed) r->lastSlot = slot;
     r->lastBlocks = blocks;
@@ -1159,7 +1159,7 @@ int pt_update_scene(PtRenderer *r, const PtGPUSphere *spheres, int num_spheres, 
       const int nbx = (v.resolution_x + 7) / 8, nby = (v.resolution_y + 7) / 8, nbz = (v.resolution_z + 7) / 8;
       const long long brickBytes = (long long)nbx * nby * nbz * 512;
       if (brickBytes <= 0x7fffffffll && (long long)nbx * nby < 32768) { // the march indexes with 32-bit integers and unsigned 24-bit factors (512 nbx nby)
-        PT_HIP_CHECK(r->dBricks.reserve((size_t)brickBytes));
+        PT_HIP_CHECK(r->dBricks.reserve((size_t)brickBytes + 16)); // the trilinear filter reads cells two bytes at a time
         const int grid = (int)std::min<long long>((brickBytes / 4 + 255) / 256, 65536);
         hipLaunchKernelGGL(ptdev::pt_brick_volume_kernel, dim3(grid), dim3(256), 0, r->stream[0], (const uint8_t *)r->dVoxels.p,
                            (uint8_t *)r->dBricks.p, v.resolution_x, v.resolution_y, v.resolution_z, nbx, nby, nbz);

@@ -1097,7 +1097,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           float volumeAlpha = 0.0f;
           if (VOLUME && L.numVolumes > 0) {
             unsigned int marchSteps;
-            const V3 vol = march_volume<false, false>(P, L, s_div255, [&]() -> float4 { return PT_MAT(L.volMaterial, 4); }, rO, curD,
+            const V3 vol = march_volume<false, 0>(P, L, s_div255, [&]() -> float4 { return PT_MAT(L.volMaterial, 4); }, rO, curD,
                                         hitAny ? bestT : kMaxDistance, marchSteps);
             volX = vol.x; volY = vol.y; volZ = vol.z;
             if (COUNT) cVoxel += marchSteps;

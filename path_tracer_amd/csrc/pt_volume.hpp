@@ -15,18 +15,31 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
 }
 
+// x / 255.0f for 0 <= x <= 255 (an interpolated voxel byte), correctly rounded like the division itself: the product
+// with the rounded reciprocal, corrected once through the exact remainder.  Checked against the division for every
+// float in [0, 255] (tests/test_div255_exact.py): three instructions instead of the eleven of a division.
+__device__ __forceinline__ float div255(float x) {
+  const float rc = 1.0f / 255.0f;
+  const float q = x * rc;
+  const float r = __builtin_fmaf(-255.0f, q, x);
+  return __builtin_fmaf(r, rc, q);
+}
+
 // P: the kernel's argument (pointers are read from it), L: the copy of the frame constants the kernel reads scalars
 // from (the same object, or its copy in LDS), s_div255: the table b / 255 for b = 0 .. 255 in LDS, materialRow4():
 // row 4 of the volume's material (colour, absorption coefficient).  Returns rayMarchVolume's colour ((-1,-1,-1): nothing there)
 // and the number of samples taken.
 // WIDE: trips of eight samples, two per packed operation, where every lane is inside the box (for a kernel with
 // registers to spare; the general kernel takes four, one at a time).
-// FAST: the caller has checked that the volume is the common case -- nearest-neighbour filter, bricked copy, every
-// extent a power of two, v0 = (0,0,0) (the reference's volume: box (0,0,0)-(2,2,2)) -- so the code for the other
-// cases, and the wave-uniform branches that choose between them per sample, are not compiled in (x - 0 is x).
-template <bool WIDE, bool FAST, class MaterialRow>
+// KIND 1 / 2: the caller has checked that the volume is the common case -- bricked copy, every extent a power of two,
+// v0 = (0,0,0) (the reference's volume: box (0,0,0)-(2,2,2)) -- and the filter is the nearest-neighbour one (1) or the
+// trilinear one (2), so the code for the other cases, and the wave-uniform branches that choose between them per
+// sample, are not compiled in (x - 0 is x).  KIND 0: everything is decided at run time.
+template <bool WIDE, int KIND, class MaterialRow>
 __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FrameParams &L, const float *s_div255, MaterialRow &&materialRow4,
                                            const V3 rO, const V3 curD, const float maxDist, unsigned int &steps) {
+  constexpr bool FAST = KIND == 1;  // nearest filter, common volume
+  constexpr bool COMMON = KIND != 0; // common volume, filter known
   float volX = -1.0f, volY = -1.0f, volZ = -1.0f;
   steps = 0u;
     // intersectBox (:519-532)
@@ -47,18 +60,18 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       float t = tNear;
       float acc = 0.0f;
       int stepCount = 0;
-      const V3 vpos = ld3(L.volPos), lo = FAST ? mk3(0.0f, 0.0f, 0.0f) : ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
+      const V3 vpos = ld3(L.volPos), lo = COMMON ? mk3(0.0f, 0.0f, 0.0f) : ld3(L.v0), hi = ld3(L.v1), ext = ld3(L.extent);
       const float rcpEx = L.rcpExtent[0], rcpEy = L.rcpExtent[1], rcpEz = L.rcpExtent[2];
       const float cellTolX = 1.5f * 0x1p-22f * (float)L.res[0], cellTolY = 1.5f * 0x1p-22f * (float)L.res[1],
                   cellTolZ = 1.5f * 0x1p-22f * (float)L.res[2];
       const uint8_t *__restrict__ vox = P.voxels;
-      const bool exactExtent = FAST || L.exactExtent != 0;
-      const bool bricked = FAST || P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
+      const bool exactExtent = COMMON || L.exactExtent != 0;
+      const bool bricked = COMMON || P.brickX > 0; // 8x8x8-voxel bricks, 512 bytes each, x fastest inside and between bricks
       const int nbx = P.brickX, nby = P.brickY;
-      if (!FAST && L.volumeFilter == 1) {
+      if (KIND == 2 || (KIND == 0 && L.volumeFilter == 1)) {
         // Trilinear extension: voxel centres at (i + 0.5) / res; lerp(a, b, t) =
         // fma(t, b - a, a) along x, then y, then z on the byte values, then / 255.
-        const bool brk = P.brickX > 0;
+        const bool brk = COMMON || P.brickX > 0;
         const int bX = P.brickX, bY = P.brickY;
         auto fetch = [&](int ix, int iy, int iz) -> float {
           const int id = brk ? ((((iz >> 3) * bY + (iy >> 3)) * bX + (ix >> 3)) << 9) +
@@ -79,9 +92,13 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
           tsT[0] = t;
 #pragma unroll
           for (int s = 1; s < kTri; ++s) tsT[s] = tsT[s - 1] + 0.02f;
-          unsigned int cell[kTri][8];
+          // The two cells of a sample that differ in x only are neighbours in memory (x runs fastest in the linear copy
+          // and inside a brick), so one 16-bit load fetches both: four loads per sample instead of eight.  Where
+          // the upper cell starts the next brick (ix & 7 = 7, 1 lane in 8) its byte is fetched on its own; where it
+          // is the clamped copy of the lower one (ix = res - 1) the weight f is 0 and the second byte does not matter.
+          unsigned int base[kTri][4], xStep[kTri];
           float f[kTri][3];
-          bool inside[kTri];
+          bool inside[kTri], lone[kTri];
 #pragma unroll
           for (int s = 0; s < kTri; ++s) {
             const V3 rel = sub3(madd3(rO, tsT[s], curD), vpos);
@@ -97,33 +114,54 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
             for (int a = 0; a < 3; ++a) {
               const float p = u[a] * rf[a] - 0.5f;
               const float top = (float)(ri[a] - 1);
-              float q = p < 0.0f ? 0.0f : (p > top ? top : p);
-              if (q != q) q = 0.0f;
+              // p < 0 ? 0 : (p > top ? top : p), and 0 for a p that is not a number, in one instruction (the median of
+              // (p, 0, top); a -0 it may return where the comparisons give +0 has the same cell and weight 0 either way)
+              const float q = __builtin_amdgcn_fmed3f(p, 0.0f, top);
               const int i0 = (int)q;
-              f[s][a] = q - (float)i0;
+              f[s][a] = __builtin_amdgcn_fractf(q); // q - floor(q), exact for q >= 0: the same as q - float(int(q))
               const int i1 = i0 + 1 > ri[a] - 1 ? ri[a] - 1 : i0 + 1;
               const int lin = a == 0 ? 1 : (a == 1 ? rx : rx * ry);
               const int shift = 3 * a, step = a == 0 ? 504 : (a == 1 ? rowStep : sliceStep);
               term[0][a] = brk ? (i0 << shift) + (int)__umul24((unsigned int)(i0 >> 3), (unsigned int)step) : i0 * lin;
               term[1][a] = brk ? (i1 << shift) + (int)__umul24((unsigned int)(i1 >> 3), (unsigned int)step) : i1 * lin;
+              if (a == 0) lone[s] = brk && (i0 & 7) == 7 && i1 != i0;
             }
+            xStep[s] = (unsigned int)(term[1][0] - term[0][0]);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) cell[s][c] = (unsigned int)(term[c & 1][0] + term[(c >> 1) & 1][1] + term[c >> 2][2]);
+            for (int c = 0; c < 4; ++c) base[s][c] = (unsigned int)(term[0][0] + term[c & 1][1] + term[c >> 1][2]);
           }
-          float b[kTri][8];
+          unsigned int pair[kTri][4];
 #pragma unroll
           for (int s = 0; s < kTri; ++s)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) b[s][c] = (float)vox[cell[s][c]];
+            for (int c = 0; c < 4; ++c) {
+              unsigned short v; // any byte address: the device reads unaligned words of global memory
+              __builtin_memcpy(&v, vox + base[s][c], 2);
+              pair[s][c] = v;
+            }
+          bool anyLone = false;
+#pragma unroll
+          for (int s = 0; s < kTri; ++s) anyLone = anyLone || lone[s];
+          if (ballot64(anyLone) != 0ull) {
+#pragma unroll
+            for (int s = 0; s < kTri; ++s)
+              if (lone[s]) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pair[s][c] = (pair[s][c] & 0xFFu) | ((unsigned int)vox[base[s][c] + xStep[s]] << 8);
+              }
+          }
           const int stepsBefore = stepCount;
 #pragma unroll
           for (int s = 0; s < kTri; ++s) {
             // t only grows, so a sample that is not taken ends the lane's march (the ones after it are not taken either)
             const bool taken = s == 0 || (tsT[s] < tFar && stepsBefore + s < 500);
-            const float c00 = __builtin_fmaf(f[s][0], b[s][1] - b[s][0], b[s][0]), c10 = __builtin_fmaf(f[s][0], b[s][3] - b[s][2], b[s][2]);
-            const float c01 = __builtin_fmaf(f[s][0], b[s][5] - b[s][4], b[s][4]), c11 = __builtin_fmaf(f[s][0], b[s][7] - b[s][6], b[s][6]);
+            float b[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { b[2 * c] = (float)(pair[s][c] & 0xFFu); b[2 * c + 1] = (float)((pair[s][c] >> 8) & 0xFFu); }
+            const float c00 = __builtin_fmaf(f[s][0], b[1] - b[0], b[0]), c10 = __builtin_fmaf(f[s][0], b[3] - b[2], b[2]);
+            const float c01 = __builtin_fmaf(f[s][0], b[5] - b[4], b[4]), c11 = __builtin_fmaf(f[s][0], b[7] - b[6], b[6]);
             const float c0 = __builtin_fmaf(f[s][1], c10 - c00, c00), c1 = __builtin_fmaf(f[s][1], c11 - c01, c01);
-            const float density = inside[s] ? __builtin_fmaf(f[s][2], c1 - c0, c0) / 255.0f : 0.0f;
+            const float density = inside[s] ? div255(__builtin_fmaf(f[s][2], c1 - c0, c0)) : 0.0f;
             const float next = __builtin_fmaf(1.0f - acc, density * absorptionCoeff, acc);
             acc = taken ? next : acc;
             stepCount += taken ? 1 : 0;
@@ -201,7 +239,7 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
       // rounding error is below 3e-7 of them), hence so does everything between them.  The stretch leaves out
       // the first and the last hundredth of the chord, where the entry and exit faces are closer than that.
       float tSafeA = kMaxDistance, tSafeB = -kMaxDistance;
-      if (exactExtent && (FAST || L.volumeFilter != 1)) {
+      if (KIND != 2 && exactExtent && (FAST || L.volumeFilter != 1)) {
         const float ta = tNear + 0.01f, tb = tFar - 0.01f;
         const V3 pa = sub3(madd3(rO, ta, curD), vpos), pb = sub3(madd3(rO, tb, curD), vpos);
         const float mx = 1e-5f * (__builtin_fabsf(rO.x) + __builtin_fabsf(vpos.x) + __builtin_fabsf(lo.x) + __builtin_fabsf(hi.x) + tFar * __builtin_fabsf(curD.x));
@@ -366,8 +404,8 @@ __device__ __forceinline__ void write_pixel(const FrameParams &P, const int accu
 // 672-679).  One wave per 8x8 tile, four tiles per workgroup, no state machine and no tickets: the kernel needs a
 // third of the general kernel's registers, so twice as many waves are resident to cover the latency of the voxel
 // loads, which is what bounds the march there.
-// FAST: see march_volume; the host launches that variant where the volume qualifies.
-template <bool FAST>
+// KIND: see march_volume; the host launches the variant the volume and the filter qualify for.
+template <int KIND>
 __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams P) {
   __shared__ float s_div255[256];
   s_div255[threadIdx.x] = (float)threadIdx.x / 255.0f; // the workgroup has 256 threads
@@ -380,7 +418,7 @@ __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams 
   V3 fin = mk3(0, 0, 0);
   float thr = 1.0f;
   unsigned int steps;
-  const V3 vol = march_volume<true, FAST>(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
+  const V3 vol = march_volume<true, KIND>(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
                               kMaxDistance, steps);
   float volumeAlpha = 0.0f;
   if (vol.x >= 0.0f) volumeAlpha = glclamp(length3(vol) / length3(mk3(1.0f, 1.0f, 1.0f)), 0.0f, 1.0f); // :618-620
