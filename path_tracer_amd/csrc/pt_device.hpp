@@ -49,6 +49,20 @@ enum : int {
   ST_WAIT = 7        // all of this lane's lighting rays are with other lanes; it casts none itself this pass
 };
 
+// calculateLighting skips an emissive object unless alignment = dot(N, (c - p) / |c - p|) > 0 (raytrace.comp:417-421,
+// 452-455).  True where that alignment, computed in float32 exactly as the shader computes it, is certain to be <= 0,
+// from a = dot(N, c - p) alone: with t = c - p (the same subtraction), S = sum |N_i t_i| and u = 2^-24, the three
+// quotients t_i / |t| carry a relative error of at most u each and the two dot products at most 3.1 u S each (scaled by
+// |t| > 0), so alignment |t| <= a + 7.2 u S; a < -(2^-20 S + 1e-30) leaves it negative (1e-30: products that
+// underflow).  A NaN anywhere makes the comparison false: such entries take the shader's own arithmetic.
+__device__ __forceinline__ bool turned_away(const V3 c, const V3 p, const V3 n) {
+  const V3 t = sub3(c, p);
+  const float a = dot3(n, t);
+  const float S = __builtin_fmaf(__builtin_fabsf(n.z), __builtin_fabsf(t.z),
+                                 __builtin_fmaf(__builtin_fabsf(n.y), __builtin_fabsf(t.y), __builtin_fabsf(n.x) * __builtin_fabsf(t.x)));
+  return __builtin_fmaf(0x1p-20f, S, a) < -1.0e-30f;
+}
+
 // MODE 0: the production kernel.  MODE 1: also counts rays, tests, roots and
 // wave trips (what the oracle counts, for parity checks and the bench's ray
 // count).  MODE 2: production code plus per-phase cycle sums per wave (kept
@@ -972,6 +986,12 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       if (step == GO_NEXT_EM_SPHERE) do { // raytrace.comp:367-443, over the precomputed emissive list
         step = GO_NEXT_EM_ELLIPSOID;
         while (k < L.numEmSpheres) {
+          // The lanes of a wave stand at different entries of the list, and the loop body below costs the wave the
+          // same for one lane as for sixty-four, once per entry the slowest lane has to pass over.  So each lane first
+          // runs over the entries that surely do not face its hit point (a few instructions each), and the body is
+          // then taken by all lanes together, each at the first entry it could not rule out.
+          while (k < L.numEmSpheres && turned_away(xyz(PT_EMS(k, 0)), hitP, hitN) && __float_as_int(PT_EMS(k, 2).x) == 0) k++;
+          if (!(k < L.numEmSpheres)) break;
           const float4 s = PT_EMS(k, 0), sm = PT_EMS(k, 1), sx = PT_EMS(k, 2);
           const int si = __float_as_int(sx.y);
           if (si >= Ns) { k = L.numEmSpheres; break; }
@@ -1025,6 +1045,8 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       if (step == GO_NEXT_EM_ELLIPSOID) do { // raytrace.comp:445-480
         step = GO_AFTER_LIGHTING;
         while (k < L.numEmEllipsoids) {
+          while (k < L.numEmEllipsoids && turned_away(xyz(PT_EME(k, 0)), hitP, hitN)) k++; // as for the spheres
+          if (!(k < L.numEmEllipsoids)) break;
           const float4 e0 = PT_EME(k, 0), em = PT_EME(k, 1), ex = PT_EME(k, 2);
           const int ei = __float_as_int(ex.x);
           if (ei >= Ne) { k = L.numEmEllipsoids; break; }

@@ -67,3 +67,31 @@ def test_formula_agrees_with_libm_powf():
     ok = g >= np.float32(1.2e-38)
     assert int(_ulps(mine[ok], g[ok]).max()) <= 1
     assert float((mine[ok] != g[ok]).mean()) < 5e-3
+
+
+def whole_power(x, n):
+    """The kernel's route for whole exponents: square and multiply in double precision, one rounding to float32."""
+    b = x.astype(np.float64)
+    r = np.ones_like(b)
+    n = n.astype(np.int64).copy()
+    with np.errstate(over="ignore", under="ignore"):
+        while np.any(n > 1):
+            odd = (n > 1) & ((n & 1) == 1)
+            r = np.where(odd, r * b, r)
+            b = np.where(n > 1, b * b, b)
+            n = np.where(n > 1, n >> 1, n)
+        return (r * b).astype(np.float32)
+
+
+def test_square_and_multiply_is_the_correctly_rounded_power_for_whole_exponents():
+    rng = np.random.default_rng(3)
+    n = 300_000
+    x = np.concatenate([rng.random(n), 1 - rng.random(n) * 1e-3, rng.uniform(1, 3, n)]).astype(np.float32)
+    x = np.maximum(x, np.float32(1e-38))
+    y = np.concatenate([rng.choice([1, 2, 3, 16, 32, 128, 4096], n), rng.integers(1, 4097, n), rng.integers(1, 200, n)]).astype(np.float32)
+    mine = whole_power(x, y)
+    with np.errstate(over="ignore", under="ignore"):
+        ref = np.power(x.astype(np.longdouble), y.astype(np.longdouble)).astype(np.float32)
+    ok = np.isfinite(ref)
+    # also where the result is a float32 denormal or underflows to 0: the double-precision product is rounded once
+    assert np.array_equal(mine[ok], ref[ok])

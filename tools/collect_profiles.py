@@ -7,6 +7,7 @@ Outputs (all text, small):
   <round>_bench.json          the bench.py line of that run
   <round>_kernel_trace.txt    rocprofv3 --kernel-trace --stats of the same bench command: per-kernel calls / total / average
   <round>_pmc.txt             per-dispatch PMC sums for workloads c2, c3, c4 (SQ pass, FETCH_SIZE pass, WRITE_SIZE pass)
+  <round>_two_in_flight_trace.txt  begin / end stamps of the timed kernel in the default mode (two frames in flight)
   <round>_traffic.json        FETCH_SIZE / WRITE_SIZE per launch of the timed kernel, in bytes (rocprofv3 reports KiB)
 """
 import glob
@@ -36,6 +37,36 @@ def kernel_counter(db, counter, kernels=TIMED_KERNELS):
     return acc / max(len(disp), 1)
 
 
+def two_in_flight(db, path):
+    """Begin / end stamps of the timed kernel in the default mode (frames in flight): how the launches overlap."""
+    con = sqlite3.connect(db)
+    rows = list(con.execute("select queue_id, start, end from kernels where name like '%pt_render_kernel<0%' order by start"))
+    if not rows:
+        return
+    t0 = rows[0][1]
+    # the first run of alternating queues is the timed region of the headline (frames go round two slots)
+    run = []
+    for q, s, e in rows:
+        if run and q == run[-1][0]:
+            if len(run) >= 8:
+                run.pop()  # that launch already belongs to what follows (frames drawn one at a time)
+                break
+            run = []
+        run.append((q, s, e))
+    both = 0
+    for i in range(1, len(run)):
+        both += max(0, min(run[i - 1][2], run[i][2]) - run[i][1])
+    span = run[-1][2] - run[0][1]
+    with open(path, "w") as f:
+        f.write("# rocprofv3 --kernel-trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras (default: two frames in flight)\n")
+        f.write("# pt_render_kernel<0,...> launches of the first region whose frames alternate between two hardware queues; microseconds from its first launch\n")
+        f.write(f"# {len(run)} launches in {span / 1e3:.1f} us = {span / 1e3 / len(run):.1f} us per frame; two kernels run side by side "
+                f"{both / span:.2f} of that time; a kernel takes {sum(e - s for _, s, e in run) / len(run) / 1e3:.1f} us from begin to end\n")
+        f.write("# queue   begin     end  duration\n")
+        for q, s, e in run:
+            f.write(f"{q:7d} {(s - run[0][1]) / 1e3:7.1f} {(e - run[0][1]) / 1e3:7.1f} {(e - s) / 1e3:9.1f}\n")
+
+
 def main():
     src, rnd = sys.argv[1], sys.argv[2]
     out = os.path.join(os.path.dirname(HERE), "profiles")
@@ -61,6 +92,9 @@ def main():
                     sys.argv = ["pmc_summary", d]
                     pmc_summary.main()
                 f.write(f"# same, --workload {wl} --steps 3 --warmup 1\n" + b2.getvalue())
+    tdb = glob.glob(os.path.join(src, "trace_two_in_flight", "*_results.db"))
+    if tdb:
+        two_in_flight(tdb[0], os.path.join(out, f"{rnd}_two_in_flight_trace.txt"))
     buf = io.StringIO()
     with redirect_stdout(buf):
         for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):

@@ -3,6 +3,7 @@
 #   1. the default bench line (bench.py --steps 10 --warmup 2)
 #   2. rocprofv3 --kernel-trace --stats of the same command with --frames-in-flight 1 (the mode the roofline object
 #      describes: kernels of consecutive frames do not overlap, a launch's duration is that of a kernel running alone)
+#   2b. rocprofv3 --kernel-trace of the default mode (two frames in flight): the kernels' begin and end stamps
 #   3. PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE, L2 hit/miss/request counters — one pass each) for workloads c2, c3, c4
 set -u
 tag=$1
@@ -12,6 +13,8 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2"
 timeout -k 10 600 $BENCH > $out/bench.json 2> $out/bench.err || { echo bench failed; tail -5 $out/bench.err; exit 1; }
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats -d $out/trace_bench -o t -- $BENCH --no-cpu --no-extras --frames-in-flight 1 > $out/trace_bench.log 2>&1 || { echo trace failed; exit 1; }
+# the headline mode (two frames in flight): begin / end stamps of the kernels, for the overlap
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats -d $out/trace_two_in_flight -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu --no-extras > $out/trace_two_in_flight.log 2>&1 || { echo trace two in flight failed; exit 1; }
 for wl in c2 c3 c4; do
   B="python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --no-extras --no-cpu --frames-in-flight 1"
   if [ $wl != c2 ]; then
