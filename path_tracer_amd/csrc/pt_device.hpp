@@ -990,7 +990,9 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           // same for one lane as for sixty-four, once per entry the slowest lane has to pass over.  So each lane first
           // runs over the entries that surely do not face its hit point (a few instructions each), and the body is
           // then taken by all lanes together, each at the first entry it could not rule out.
-          while (k < L.numEmSpheres && turned_away(xyz(PT_EMS(k, 0)), hitP, hitN) && __float_as_int(PT_EMS(k, 2).x) == 0) k++;
+          // (Not in the variant for scenes with hundreds of spheres: a pass over those dwarfs this loop, and the registers
+          // the run-ahead holds there are spilled ones.)
+          if (!POOLED) while (k < L.numEmSpheres && turned_away(xyz(PT_EMS(k, 0)), hitP, hitN) && __float_as_int(PT_EMS(k, 2).x) == 0) k++;
           if (!(k < L.numEmSpheres)) break;
           const float4 s = PT_EMS(k, 0), sm = PT_EMS(k, 1), sx = PT_EMS(k, 2);
           const int si = __float_as_int(sx.y);
@@ -1045,7 +1047,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       if (step == GO_NEXT_EM_ELLIPSOID) do { // raytrace.comp:445-480
         step = GO_AFTER_LIGHTING;
         while (k < L.numEmEllipsoids) {
-          while (k < L.numEmEllipsoids && turned_away(xyz(PT_EME(k, 0)), hitP, hitN)) k++; // as for the spheres
+          if (!POOLED) while (k < L.numEmEllipsoids && turned_away(xyz(PT_EME(k, 0)), hitP, hitN)) k++; // as for the spheres
           if (!(k < L.numEmEllipsoids)) break;
           const float4 e0 = PT_EME(k, 0), em = PT_EME(k, 1), ex = PT_EME(k, 2);
           const int ei = __float_as_int(ex.x);
