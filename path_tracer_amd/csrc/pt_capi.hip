@@ -164,6 +164,7 @@ struct PtRenderer {
   //   bit 25      frames without solids on the general kernel, not the volume kernel
   //   bit 26      (instrumented phase kernel) per-phase and per-ticket clock stamps
   //   bits 27-29  n > 0: launch 1/2^(n-1) of the resident workgroups whatever is in flight
+  //   bit 30      a lane whose lighting rays are all with helpers does not cast its next path ray in the same pass
   int tune = 0;
   void *extRgba8[kMaxSlots] = {}, *extF32[kMaxSlots] = {}; // caller-owned output per slot (pt_set_output: slot 0, pt_set_slot)
   bool floatOutput = true;

@@ -1,3 +1,7 @@
+"""python tools/probes/phase_sweep.py <lib.so>: share of wave time per phase of a C2 pass, with the shading sweep split
+into its parts.  For a measurement build of the library whose phase stamps are placed that way (counters 13-17, 21,
+22: refill, spheres + exact routine, ellipsoids, path result, results of the lighting rays, next lighting ray, the
+rest); the committed library stamps refill / spheres / ellipsoids / shading / exact routine (tools/probes/phase.py)."""
 import sys, numpy as np
 sys.path.insert(0,'.')
 from path_tracer_amd import _lib
