@@ -72,6 +72,34 @@ def test_trilinear_filter_matches_oracle_trilinear(oracle):
     assert (ref8 != near8).any()  # the filter changes the picture
 
 
+@pytest.mark.parametrize("box", [((0.0, 0.0, 0.0), (2.0, 2.0, 2.0)),        # the common volume: the kernel variants compiled for it
+                                 ((0.25, -0.5, 0.125), (2.25, 1.5, 2.125)),  # box off the volume's position, extents 2
+                                 ((0.0, 0.0, 0.0), (1.7, 2.3, 1.9)),         # extents that are no powers of two
+                                 ((-0.3, 0.1, 0.0), (1.5, 2.0, 2.4))])
+@pytest.mark.parametrize("filt", [0, 1])
+def test_every_variant_of_the_volume_kernel_against_the_oracle(oracle, box, filt):
+    """The kernel for frames without solids is compiled for the common volume (bricked, power-of-two extents, box at
+    v0 = 0), once per filter, and once with everything decided at run time; a linear copy takes the last one too.
+    Each must give the oracle's frame bit for bit (no pow / cos on this path), from outside and from inside the box."""
+    res = (70, 50, 61)
+    vox = (scenes.synthetic_walnut(res) // 6).astype(np.uint8)
+    for cam in ((5.0, 1.5, 6.0), (2.4, 1.9, 0.3)):  # the second camera stands inside the box
+        sc = scenes.config4(320, 180, voxels=vox, resolution=res)
+        sc.volumes["v0"][0][:3] = box[0]
+        sc.volumes["v1"][0][:3] = box[1]
+        sc.camera_pos = cam
+        pc = sc.push_constants()
+        ref8, reff, refc = oracle.render(sc, nthreads=16, volume_filter=filt)
+        assert int(refc[6]) > 0  # voxel samples: the rays do meet the volume
+        for bricks in (1, 0):
+            r = _renderer(sc, {T.OPT_VOLUME_FILTER: filt, T.OPT_VOLUME_BRICKS: bricks})
+            g8, gf = _frame(r, pc)
+            assert r.lastLaunch()[1] == 256 and r.lastLaunch()[2] == 1024  # the volume kernel's launch
+            r.shutdown()
+            np.testing.assert_array_equal(gf.view(np.uint32), reff.view(np.uint32))
+            np.testing.assert_array_equal(g8, ref8)
+
+
 def test_trilinear_with_solids_within_tolerance(oracle):
     res = (40, 30, 36)
     vox = scenes.synthetic_walnut(res)
