@@ -560,7 +560,7 @@ def main():
                 extras[name]["trilinear"] = {
                     "ms_per_frame": round(dt_ / steps * 1e3, 4), "Msamples_per_s": round(ct[6] / (dt_ / steps) / 1e6, 2),
                     "requested_GBs": round(ct[6] * 8 / (et_ / steps * 1e-3) / 1e9, 1),
-                    "note": "PT_OPT_VOLUME_FILTER = 1: 8 one-byte voxel fetches per sample, bricked volume"}
+                    "note": "PT_OPT_VOLUME_FILTER = 1: 8 voxel bytes per sample (four 16-bit fetches, the two cells along x together), bricked volume"}
         if args.workload != "c5":
             # 64 samples per pixel at 4K (C2's objects + the volume): one launch per sample, running mean on the device
             sc = build_scene("c5")
