@@ -387,8 +387,10 @@ def dynamic_loop(device: int, frames: int = 120):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 200 frames: with frames in flight the timed region holds one pipeline fill and one tail whatever K is
+    # (0.50 ms per frame at K = 10, 0.46 at 20, 0.42 from 100 on), and a region of 9 ms is short for a wall clock
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (testing only; 1.0 = the named config)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3/C4/C5 side measurements")
