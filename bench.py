@@ -354,7 +354,8 @@ def dynamic_loop(device: int, frames: int = 120):
         e["rotation"] = scenes.axis_angle_quat((2.0, 1.0, 0.0), (k + 1) / 180.0)
         ells.append(e)
 
-    def run(update: bool, present_each: bool):
+    def run(update: bool, present_each: bool, lag: int = 0):
+        r.setOption(8, lag)  # PT_OPT_PRESENT_LAG
         for k in range(4):
             r.render(pcs[k])
         r.present()
@@ -378,6 +379,17 @@ def dynamic_loop(device: int, frames: int = 120):
         out[mode] = {"update_and_render_ms_per_frame": round(dyn_wall, 4), "render_only_ms_per_frame": round(sta_wall, 4),
                      "ratio": round(dyn_wall / sta_wall, 3), "update_and_render_event_ms": round(dyn_ev, 4),
                      "render_only_event_ms": round(sta_ev, 4)}
+    # the same loop with PT_OPT_PRESENT_LAG = 1: present() waits for the frames before the one just queued
+    run(True, True, 1)
+    dyn_wall, dyn_ev = run(True, True, 1)
+    sta_wall, sta_ev = run(False, True, 1)
+    out["present_every_frame_lag_1"] = {
+        "update_and_render_ms_per_frame": round(dyn_wall, 4), "render_only_ms_per_frame": round(sta_wall, 4),
+        "ratio": round(dyn_wall / sta_wall, 3), "update_and_render_event_ms": round(dyn_ev, 4),
+        "render_only_event_ms": round(sta_ev, 4),
+        "note": "PT_OPT_PRESENT_LAG = 1 (an extension): present() after render() waits for the earlier frames only and "
+                "shows the frame before the one just queued"}
+    r.setOption(8, 0)
     r.shutdown()
     out["note"] = ("updateScene rebuilds the host copy of the scene and each frame slot refreshes its device copy on its own "
                    "stream (pinned staging, hipMemcpyAsync) in front of its next frame: no wait for the frames in flight")

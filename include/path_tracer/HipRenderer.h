@@ -107,6 +107,14 @@ public:
     if (handle_) pt_set_option(handle_, PT_OPT_HONOUR_MAX_DEPTH, on ? 1 : 0);
   }
   bool honourMaxDepth() const { return honourMaxDepth_; }
+  // Extension: present() after a render() waits for the frames before that one only and the readbacks show the
+  // frame before it, so a loop of updateScene / render / present keeps one frame drawing while the host prepares the
+  // next (PT_OPT_PRESENT_LAG; the reference's present() drains the queue, src/VulkanRenderer.cpp:1355-1356, which
+  // remains the default).  A present() without a render() since the last one shows the last frame.
+  void setPresentLag(bool on) {
+    presentLag_ = on;
+    if (handle_) pt_set_option(handle_, PT_OPT_PRESENT_LAG, on ? 1 : 0);
+  }
   // False after an updateScene() that the library rejected (until one is accepted).
   bool sceneOk() const { return sceneOk_; }
 
@@ -123,6 +131,7 @@ public:
     height_ = height;
     sceneOk_ = true;
     pt_set_option(handle_, PT_OPT_HONOUR_MAX_DEPTH, honourMaxDepth_ ? 1 : 0);
+    pt_set_option(handle_, PT_OPT_PRESENT_LAG, presentLag_ ? 1 : 0);
     shaderPathToIndex_.clear();
     for (int i = 0; i < pt_shader_count(); ++i) shaderPathToIndex_[pt_shader_path(i)] = i + 1;
     return true;
@@ -259,7 +268,7 @@ private:
   PtComm *comm_ = nullptr;
   int rank_ = 0;
   int width_ = 0, height_ = 0;
-  bool honourMaxDepth_ = false, sceneOk_ = true;
+  bool honourMaxDepth_ = false, sceneOk_ = true, presentLag_ = false;
   std::vector<GPUSphere> spheres_;
   std::vector<GPUEllipsoid> ellipsoids_;
   std::vector<GPUMaterial> materials_;

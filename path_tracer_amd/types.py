@@ -120,3 +120,5 @@ OPT_TILE_ORDER = 3
 OPT_VOLUME_BRICKS = 4
 OPT_VOLUME_FILTER = 5
 OPT_FRAMES_IN_FLIGHT = 6
+OPT_HONOUR_MAX_DEPTH = 7
+OPT_PRESENT_LAG = 8

@@ -337,6 +337,39 @@ def test_launches_sized_by_the_streams_side_by_side_draw_the_same_frame():
         r.shutdown()
 
 
+def test_present_lag_shows_the_frame_before_the_one_just_queued():
+    """PT_OPT_PRESENT_LAG = 1: present() after a render() waits for the earlier frames only and the readbacks show the
+    frame before the one just queued, so the reference's loop (updateScene, render, present per frame) keeps a frame
+    drawing while the host prepares the next.  The frames are the ones a present() that drains everything shows, one
+    call later; a present() without a render() in between shows the last frame."""
+    import math
+
+    sc = scenes.config2(480, 270, n_spheres=20, n_ellipsoids=6)
+    pcs = []
+    for k in range(6):
+        pc = sc.push_constants().copy()
+        pc["cameraPos"] = (np.float32(2.0 + 3.0 * math.cos(0.2 * k)), 1.5, np.float32(6.0 + 3.0 * math.sin(0.2 * k)))
+        pcs.append(pc)
+    r = _renderer(sc)
+    want = [_frame(r, pc)[1].copy() for pc in pcs]  # drained after every frame
+    assert any((want[0] != w).any() for w in want[1:])
+    r.setOption(T.OPT_PRESENT_LAG, 1)
+    for k, pc in enumerate(pcs):
+        r.render(pc)
+        r.present()
+        shown = r.readbackF32()
+        # the frame queued before this one: for k = 0 that is the last frame of the loop above
+        np.testing.assert_array_equal(shown.view(np.uint32), want[k - 1].view(np.uint32))
+    r.present()  # nothing queued since: the last frame
+    np.testing.assert_array_equal(r.readbackF32().view(np.uint32), want[-1].view(np.uint32))
+    # one frame at a time has nothing to lag behind: the option changes nothing there
+    r.setOption(T.OPT_FRAMES_IN_FLIGHT, 1)
+    r.setOption(T.OPT_PRESENT_LAG, 1)
+    for k, pc in enumerate(pcs[:3]):
+        np.testing.assert_array_equal(_frame(r, pc)[1].view(np.uint32), want[k].view(np.uint32))
+    r.shutdown()
+
+
 @pytest.mark.parametrize("options", [{}, {T.OPT_VOLUME_FILTER: 1}, {T.OPT_VOLUME_BRICKS: 0}])
 def test_frames_without_solids_are_the_same_on_either_kernel(options):
     """A frame with a volume and no spheres or ellipsoids is drawn by a kernel of its own (camera ray, march,
