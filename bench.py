@@ -576,22 +576,29 @@ def main():
                     "requested_GBs": round(ct[6] * 8 / (et_ / steps * 1e-3) / 1e9, 1),
                     "note": "PT_OPT_VOLUME_FILTER = 1: 8 voxel bytes per sample (four 16-bit fetches, the two cells along x together), bricked volume"}
         if args.workload != "c5":
-            # 64 samples per pixel at 4K (C2's objects + the volume): one launch per sample, running mean on the device
+            # 64 samples per pixel at 4K (C2's objects + the volume), mean on the device: all samples in one launch
+            # ((tile, sample) tickets, one plane per sample, summed in sample order), and one launch per sample beside it
             sc = build_scene("c5")
             rr = Runner(sc, 0, 1, local_rank)
             c = rr.counters()  # sample 0 (the reference's sample)
             spp = 64
-            rr.r.renderSamples(rr.pc, 0, 2)
-            rr.sync()
-            t0 = time.perf_counter()
-            rr.r.renderSamples(rr.pc, 0, spp)
-            rr.sync()
-            d = time.perf_counter() - t0
+            took = {}
+            for batch in (0, 1):
+                rr.r.setOption(9, batch)  # PT_OPT_SAMPLE_BATCH
+                rr.r.renderSamples(rr.pc, 0, spp)  # untimed: the sample planes are allocated here
+                rr.sync()
+                t0 = time.perf_counter()
+                rr.r.renderSamples(rr.pc, 0, spp)
+                rr.sync()
+                took[batch] = time.perf_counter() - t0
             rr.close()
+            d = took[0]
             extras["c5"] = {"spp": spp, "ms_per_frame": round(d * 1e3, 3), "ms_per_sample": round(d / spp * 1e3, 4),
+                            "ms_per_frame_one_launch_per_sample": round(took[1] * 1e3, 3),
                             "rays_sample0": float(c[0]), "Mrays_per_s": round(c[0] * spp / d / 1e6, 2),
                             "note": "sub-pixel accumulation has no counterpart in the reference (one corner sample per "
-                                    "pixel); rays per sample taken from sample 0"}
+                                    "pixel); rays per sample taken from sample 0; PT_OPT_SAMPLE_BATCH = 0: the 64 samples "
+                                    "are one launch, 8.5 GB of sample planes"}
         result["workloads"] = extras
         result["dynamic_loop"] = dynamic_loop(local_rank)
 
@@ -617,7 +624,7 @@ def main():
                 spp = 64
                 rr = Runner(build_scene("c5"), rank, world, local_rank, torch_mod, dist, args.backend, frames_in_flight=1)
                 c = rr.counters()
-                rr.step(samples=2)
+                rr.step(samples=spp)  # untimed: the sample planes are allocated here
                 rr.sync(); rr.barrier(); rr.sync()
                 t0 = time.perf_counter()
                 rr.step(samples=spp)

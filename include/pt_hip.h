@@ -65,6 +65,10 @@ enum {
                                the host prepares the next, one frame later on the screen (0.41 instead of 0.59 ms
                                per 1080p frame of the 64-object scene).  A pt_present that no pt_render
                                preceded since the last one waits for everything and shows the last frame.   */
+  PT_OPT_SAMPLE_BATCH = 9,  /* pt_render_samples: samples drawn per launch.  0 (default): as many as fit 16 GiB of
+                               sample planes (one float4 frame per sample of the launch: 64 samples at 4K take
+                               8.5 GB); 1: one launch per sample, no planes; n > 1: at most n.  The frames are the
+                               same whatever the value (the planes are added up in sample order).              */
   PT_OPT_TILE_ORDER = 3     /* 1: a short pass before each frame sorts the 8x8 tiles so
                                that those whose pixels cast the longest chains of rays
                                are drawn first; 0: index order; 2 (default): sorted
@@ -219,8 +223,12 @@ int pt_render_static(PtRenderer *r, const PtPushConstants *pc, void *rgba8_dev, 
 /* Progressive accumulation (no counterpart in the reference, which draws one
  * sample per pixel at the pixel corner and never calls its random(), reference
  * shaders/raytrace.comp:117-119, 692-700).  Draws sub-pixel samples
- * first_sample .. first_sample + num_samples - 1, one launch each, and leaves
- * the mean of the clamped samples in the output frames.  Sample 0 is the
+ * first_sample .. first_sample + num_samples - 1 and leaves the mean of the
+ * clamped samples in the output frames.  Scenes with solids draw several
+ * samples per launch (PT_OPT_SAMPLE_BATCH): the launch hands out (tile, sample)
+ * pairs, so the chip idles at the end of the call instead of at the end of
+ * every sample; each sample's clamped colours go to a plane of their own and
+ * are added up in sample order, which gives the sum launches one by one give.  Sample 0 is the
  * reference's sample; sample s > 0 is offset inside the pixel by a
  * counter-based hash of (pixel, s).  keep != 0 adds to the sum of the previous
  * call instead of starting a new one.  pt_render is (0, 1, 0). */

@@ -141,6 +141,9 @@ struct PtRenderer {
   bool volumeBricks = true;                  // PT_OPT_VOLUME_BRICKS
   int volumeFilter = 0;                      // PT_OPT_VOLUME_FILTER
   DevBuf dAccum;                             // float4 sum per pixel (pt_render_samples)
+  DevBuf dPlanes;                            // pt_render_samples, several samples per launch: one float4 plane per sample
+  int sampleBatch = 0;                       // PT_OPT_SAMPLE_BATCH: samples per launch at most (0: as many as fit kPlaneBudget, 1: one)
+  int batchSamples = 1;                      // samples the next launch draws (set by pt_render_samples)
   DevBuf dWaveLog;                           // pt_wave_timeline: 4 words per wave
   bool wantWaveLog = false;
   int accumCount = 0;                        // samples in dAccum
@@ -198,6 +201,7 @@ namespace {
 
 // dScratch: class counts (3 x 4 B) at +16, counters (PT_CNT_COUNT x 8 B) at +64, tile-ticket counters at +512
 static_assert(64 + PT_CNT_COUNT * sizeof(uint64_t) <= 512, "the work counters must end before the ticket counters");
+constexpr size_t kPlaneBudget = (size_t)16 << 30; // pt_render_samples: device memory the sample planes of one launch may take
 constexpr size_t kScratchBytes = 512 + (size_t)ptdev::kTicketGroups * ptdev::kTicketStride * sizeof(unsigned int);
 
 int compute_local_rows(int height, int bandRows, int bandIndex, int bandCount) {
@@ -531,10 +535,20 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   P.ellScale = r->ellScale;
   P.volumeFilter = r->volumeFilter;
   P.sampleIndex = r->sampleIndex;
+  P.sampleCount = 1;
+  const size_t framePixels = (size_t)r->width * (size_t)std::max(r->localRows, 1);
+  const bool planes = r->accumulate && !fixed && mode == 0 && r->batchSamples > 1;
   if (r->accumulate && !fixed) {
-    PT_HIP_CHECK(r->dAccum.reserve((size_t)r->width * (size_t)std::max(r->localRows, 1) * sizeof(float4)));
+    PT_HIP_CHECK(r->dAccum.reserve(framePixels * sizeof(float4)));
     P.accum = (float4 *)r->dAccum.p;
     P.accumCount = r->accumCount + 1;
+  }
+  if (planes) { // the launch draws batchSamples samples into planes; pt_sum_samples_kernel adds them to dAccum below
+    PT_HIP_CHECK(r->dPlanes.reserve(framePixels * sizeof(float4) * (size_t)r->batchSamples));
+    P.accum = (float4 *)r->dPlanes.p;
+    P.accumCount = 0;
+    P.sampleCount = r->batchSamples;
+    P.planeStride = (int)framePixels;
   }
   P.tune = r->tune;
   // Directions longer than 1 by more than this take the exact routine (too many spheres would be candidates);
@@ -557,7 +571,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
     const double passCost = 600.0 + 5.8 * pc->numSpheres + 9.0 * pc->numEllipsoids;
     P.refillMin = std::max(1, std::min(24, (int)(16000.0 / passCost)));
   }
-  long long wavesNeeded = ((long long)P.numTiles * ptdev::kTilePixels + 63) / 64;
+  long long wavesNeeded = ((long long)P.numTiles * P.sampleCount * ptdev::kTilePixels + 63) / 64;
   long long blocksNeeded = (wavesNeeded * 64 + threads - 1) / threads;
   int blocks = (int)std::min<long long>((long long)r->computeUnits * blocksPerCu, std::max<long long>(blocksNeeded, 1));
   // Frames in flight share the chip.  A frame with few tiles per wave (one rank's share of a split) is nearly all
@@ -594,25 +608,34 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   if (P.waveLog && (size_t)blocks * (size_t)(threads / 64) * 32 > r->dWaveLog.cap)
     return fail(PT_ERR_STATE, "pt_wave_timeline: the launch has more waves than the log holds");
   dim3 grid(blocks), block(threads);
-#define PT_LAUNCH_K(MODE_, LDS_, POOLED_, VOLUME_)                                                                     \
+#define PT_LAUNCH_K(MODE_, LDS_, POOLED_, VOLUME_, SAMPLES_)                                                           \
   {                                                                                                                    \
     if (LDS_)                                                                                                          \
-      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, LDS_, POOLED_, VOLUME_>,           \
+      PT_HIP_CHECK(hipFuncSetAttribute((const void *)ptdev::pt_render_kernel<MODE_, LDS_, POOLED_, VOLUME_, SAMPLES_>, \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                    \
-    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, LDS_, POOLED_, VOLUME_>), grid, block, ldsBytes, stream, P);    \
+    hipLaunchKernelGGL((ptdev::pt_render_kernel<MODE_, LDS_, POOLED_, VOLUME_, SAMPLES_>), grid, block, ldsBytes,      \
+                       stream, P);                                                                                     \
   }
-#define PT_LAUNCH(MODE_, VOLUME_)                                                                                      \
+#define PT_LAUNCH(MODE_, VOLUME_, SAMPLES_)                                                                            \
   if (useLds) {                                                                                                        \
-    if (P.coop) PT_LAUNCH_K(MODE_, true, true, VOLUME_) else PT_LAUNCH_K(MODE_, true, false, VOLUME_)                  \
+    if (P.coop) PT_LAUNCH_K(MODE_, true, true, VOLUME_, SAMPLES_) else PT_LAUNCH_K(MODE_, true, false, VOLUME_, SAMPLES_) \
   } else {                                                                                                             \
-    if (P.coop) PT_LAUNCH_K(MODE_, false, true, VOLUME_) else PT_LAUNCH_K(MODE_, false, false, VOLUME_)                \
+    if (P.coop) PT_LAUNCH_K(MODE_, false, true, VOLUME_, SAMPLES_) else PT_LAUNCH_K(MODE_, false, false, VOLUME_, SAMPLES_) \
   }
-  // the production kernel exists with and without the volume march; the instrumented ones always carry it
-  if (mode == 1) { PT_LAUNCH(1, true) } else if (mode == 2) { PT_LAUNCH(2, true) }
-  else if (pc->numVolumes > 0) { PT_LAUNCH(0, true) } else { PT_LAUNCH(0, false) }
+  // the production kernel exists with and without the volume march, and for launches of several samples; the
+  // instrumented ones always carry the march
+  if (mode == 1) { PT_LAUNCH(1, true, false) } else if (mode == 2) { PT_LAUNCH(2, true, false) }
+  else if (planes) { if (pc->numVolumes > 0) { PT_LAUNCH(0, true, true) } else { PT_LAUNCH(0, false, true) } }
+  else if (pc->numVolumes > 0) { PT_LAUNCH(0, true, false) } else { PT_LAUNCH(0, false, false) }
 #undef PT_LAUNCH
 #undef PT_LAUNCH_K
   PT_HIP_CHECK(hipGetLastError());
+  if (planes) {
+    hipLaunchKernelGGL(ptdev::pt_sum_samples_kernel, dim3((unsigned int)((framePixels + 255) / 256)), dim3(256), 0, stream,
+                       (const float4 *)r->dPlanes.p, (int)framePixels, r->batchSamples, (float4 *)r->dAccum.p, r->accumCount,
+                       P.outRgba8, P.outF32);
+    PT_HIP_CHECK(hipGetLastError());
+  }
   if (!fixed) { r->lastSlot = slot; r->slotDrawn[slot] = true; r->renderedSincePresent = true; }
   r->lastBlocks = blocks;
   r->lastThreads = threads;
@@ -817,7 +840,7 @@ void pt_destroy(PtRenderer *r) {
   (void)hipSetDevice(r->device);
   for (int k = 0; k < r->numSlots; ++k)
     if (r->stream[k]) (void)hipStreamSynchronize(r->stream[k]);
-  DevBuf *bufs[] = {&r->dVoxels, &r->dBricks, &r->dAccum, &r->dWaveLog};
+  DevBuf *bufs[] = {&r->dVoxels, &r->dBricks, &r->dAccum, &r->dPlanes, &r->dWaveLog};
   for (DevBuf *b : bufs) b->release();
   for (int k = 0; k < PtRenderer::kMaxSlots; ++k) {
     r->dRgba8[k].release(); r->dF32[k].release(); r->dScratch[k].release(); r->dTileOrder[k].release();
@@ -1253,15 +1276,35 @@ int pt_render_samples(PtRenderer *r, const PtPushConstants *pc, int first_sample
   if (!r || !pc) return fail(PT_ERR_INVALID, "pt_render_samples: null argument");
   if (first_sample < 0 || num_samples < 1) return fail(PT_ERR_INVALID, "pt_render_samples: first_sample >= 0 and num_samples >= 1 required");
   if (!keep) r->accumCount = 0;
+  // Samples per launch.  One launch per sample ends every sample on its slowest pixels with most of the chip idle;
+  // a launch that draws several samples hands out (tile, sample) tickets and ends once.  Each sample of the launch
+  // needs a float4 plane of the frame (4K: 133 MB), summed up in sample order afterwards, so the result is the one the
+  // launches one by one give.  Frames without solids keep one launch per sample (the volume kernel has no tickets).
+  int batch = 1;
+  const bool volumeOnly = pc->numSpheres == 0 && pc->numEllipsoids == 0 && pc->numVolumes > 0 && !(r->tune & (1 << 25));
+  if (r->sampleBatch != 1 && num_samples > 1 && !volumeOnly) {
+    const size_t framePixels = (size_t)r->width * (size_t)std::max(r->localRows, 1);
+    size_t freeBytes = 0, totalBytes = 0;
+    PT_HIP_CHECK(hipMemGetInfo(&freeBytes, &totalBytes));
+    const size_t budget = std::min(kPlaneBudget, (freeBytes + r->dPlanes.cap) / 2); // never more than half of what is free
+    size_t fit = budget / std::max<size_t>(framePixels * sizeof(float4), 1);
+    fit = std::min(fit, (size_t)0x7fffffff / std::max<size_t>(framePixels, 1)); // plane offsets are 32-bit pixel indices
+    if (r->sampleBatch > 1) fit = std::min(fit, (size_t)r->sampleBatch);
+    batch = (int)std::max<size_t>(1, std::min<size_t>(fit, (size_t)num_samples));
+  }
   r->accumulate = true;
   int rc = PT_OK;
-  for (int s = 0; s < num_samples && rc == PT_OK; ++s) {
+  for (int s = 0; s < num_samples && rc == PT_OK;) {
+    const int n = std::min(batch, num_samples - s);
     r->sampleIndex = first_sample + s;
+    r->batchSamples = n;
     rc = launch_frame(r, pc, 0);
-    if (rc == PT_OK) r->accumCount++;
+    if (rc == PT_OK) r->accumCount += n;
+    s += n;
   }
   r->accumulate = false;
   r->sampleIndex = 0;
+  r->batchSamples = 1;
   return rc;
 }
 
@@ -1502,6 +1545,10 @@ int pt_set_option(PtRenderer *r, int option, int value) {
     if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_PRESENT_LAG takes 0 or 1");
     r->presentLag = value;
     r->shownSlot = -1;
+    return PT_OK;
+  case PT_OPT_SAMPLE_BATCH:
+    if (value < 0) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_SAMPLE_BATCH takes 0 (as many as fit), 1 (one launch per sample) or the largest number of samples per launch");
+    r->sampleBatch = value;
     return PT_OK;
   case PT_OPT_VOLUME_FILTER:
     if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_VOLUME_FILTER takes 0 or 1");

@@ -71,7 +71,9 @@ __device__ __forceinline__ bool turned_away(const V3 c, const V3 p, const V3 n) 
 // that can fan lighting rays out (P.fanOut).  The host launches the one that matches; each carries only its own code.
 // VOLUME false: the variant for scenes without a volume, compiled without the march (the registers it would hold
 // through the shading sweep go to the rest of the kernel).
-template <int MODE, bool LDS_OBJECTS, bool POOLED, bool VOLUME = true>
+// SAMPLES: the variant for launches that draw several samples of every pixel (P.sampleCount > 1): the tickets are
+// (tile, sample) pairs and every sample's colours go to a plane of their own (see FrameParams::sampleCount).
+template <int MODE, bool LDS_OBJECTS, bool POOLED, bool VOLUME = true, bool SAMPLES = false>
 __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   const bool poolingOn = POOLED && P.coop != 0;
   const bool fanOutOn = !POOLED && P.fanOut != 0;
@@ -152,6 +154,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
   int groupsTried = 0; // ticket groups this wave has found drained
   int poolNext = 0, poolEnd = 0; // pixels [poolNext, poolEnd) of the tile at (poolTx, poolTy) are still to hand out
   int poolTx = 0, poolTy = 0;
+  int poolS = 0; // SAMPLES: the sample (counted from L.sampleIndex) the pool's pixels are drawn for
   bool exhausted = false;
   unsigned int nClass2 = 0, nClass1 = 0; // drawing order: tickets [0,n2) class 2, [n2,n2+n1) class 1, rest class 0
   if (P.tileOrder) {
@@ -222,8 +225,11 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
       const int nIdle = __popcll(idleMask);
       const int avail = poolEnd - poolNext;
       int nextBase = -1; // first pixel of the following tile, if one is needed and left
-      int nextTx = 0, nextTy = 0;
+      int nextTx = 0, nextTy = 0, nextS = 0;
       if (nIdle > avail && !exhausted) {
+        // tickets: one per (tile, sample) pair of the launch, the samples of a tile next to each other
+        const unsigned int nSamples = SAMPLES ? (unsigned int)__builtin_amdgcn_readfirstlane(L.sampleCount) : 1u;
+        const unsigned int numTickets = (unsigned int)P.numTiles * nSamples;
         // Tickets come from kTicketGroups counters instead of one: group g owns
         // tickets g, g + G, g + 2G, ...  A single counter would see one same-address
         // atomic per tile from every wave of the chip, and those queue for
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         if (PHASES && phaseStamps) { tTicket = __builtin_amdgcn_s_memtime(); nTickets++; }
         while (groupsTried < kTicketGroups) {
           const int g = (homeGroup + groupsTried) & (kTicketGroups - 1);
-          const unsigned int owned = ((unsigned int)P.numTiles + (unsigned int)(kTicketGroups - 1 - g)) / kTicketGroups;
+          const unsigned int owned = (numTickets + (unsigned int)(kTicketGroups - 1 - g)) / kTicketGroups;
           unsigned int *ctr = P.tileCounter + g * kTicketStride;
           bool drained = owned == 0u;
           if (!drained && groupsTried > 0)
@@ -248,11 +254,16 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           }
           ++groupsTried;
         }
-        if (t >= (unsigned int)P.numTiles) {
+        if (t >= numTickets) {
           exhausted = true;
           if (PHASES) tExhausted = __builtin_amdgcn_s_memtime();
           if (PHASES && P.waveLog) { rtDry = __builtin_amdgcn_s_memrealtime(); passesAtDry = nPasses; }
         } else {
+          if (SAMPLES) {
+            const unsigned int q = t / nSamples;
+            nextS = (int)(t - q * nSamples);
+            t = q;
+          }
           if (P.tileOrder) {
             const int at = t < nClass2 ? 2 * P.numTiles + (int)t
                            : t < nClass2 + nClass1 ? P.numTiles + (int)(t - nClass2) : (int)(t - nClass2 - nClass1);
@@ -275,8 +286,10 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
         int x, ly, gy;
         if (tile_pixel_xy(L, fromNext ? nextTx : poolTx, fromNext ? nextTy : poolTy, p, x, ly, gy)) {
           // main() + createCameraRay (raytrace.comp:686-700, 121-140)
-          curD = camera_dir(L, x, gy);
+          const int sample = SAMPLES ? (fromNext ? nextS : poolS) : 0;
+          curD = camera_dir(L, x, gy, L.sampleIndex + sample);
           outIdx = ly * L.width + x;
+          if (SAMPLES) outIdx += sample * L.planeStride;
           fin = mk3(0, 0, 0);
           thr = 1.0f;
           bounce = 0;
@@ -291,6 +304,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           poolEnd = nextBase + kTilePixels;
           poolTx = nextTx;
           poolTy = nextTy;
+          if (SAMPLES) poolS = nextS;
         }
         else poolNext = poolEnd;
       } else {
@@ -1232,7 +1246,7 @@ __global__ void __launch_bounds__(1024) pt_render_kernel(const FrameParams P) {
           }
         } while (0);
         if (step == GO_FINISH) do { // main() :703-704
-          write_pixel(P, L.accumCount, outIdx, fin);
+          write_pixel<SAMPLES>(P, L.accumCount, outIdx, fin);
           state = ST_IDLE;
           step = GO_EMITTED;
         } while (0);

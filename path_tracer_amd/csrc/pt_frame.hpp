@@ -76,7 +76,13 @@ struct FrameParams {
   int volumeFilter; // 0 nearest neighbour (raytrace.comp:485-517), 1 trilinear
   int sampleIndex;  // sub-pixel sample drawn by this launch; 0 = the reference's pixel-corner sample
   int accumCount;   // with accum: number of samples in the sum after this launch
-  float4 *accum;    // running sum of the clamped samples per pixel, or null
+  float4 *accum;    // running sum of the clamped samples per pixel, or null; in a launch of several samples: the planes
+  // Several samples in one launch (the general kernel's SAMPLES variant): the tickets run over numTiles x sampleCount
+  // (tile, sample) pairs, tile-major in drawing order, sample sampleIndex + s of a pixel goes to
+  // accum[s * planeStride + pixel] (one plane of clamped colours per sample) and pt_sum_samples_kernel adds the planes
+  // to the running sum in sample order afterwards.
+  int sampleCount;  // samples drawn by this launch, >= 1
+  int planeStride;  // pixels per plane
   int fanOut;       // 1: at the end of the frame lighting rays of one pixel are spread over idle lanes (not with coop)
   int coop;         // 1: at the end of the frame the waves of a workgroup pool their rays (see the kernel)
   float unitTol;    // dot(d,d) - 1 up to which a ray takes the dense sphere loop (longer: too many spheres are candidates)
@@ -112,11 +118,11 @@ __device__ __forceinline__ bool tile_pixel(const FrameParams &P, int tile, int w
 }
 
 // createCameraRay for pixel (x, gy) (raytrace.comp:121-140 with main()'s uv, :692-700)
-__device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) {
+__device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy, int sample) {
   float fx = (float)x, fy = (float)gy;
-  if (P.sampleIndex != 0) {
+  if (sample != 0) {
     // sub-pixel offset in [0,1)^2 from a counter-based hash of (pixel, sample)
-    uint32_t h = ((uint32_t)gy * (uint32_t)P.width + (uint32_t)x) * 0x9E3779B1u + (uint32_t)P.sampleIndex * 0x85EBCA77u;
+    uint32_t h = ((uint32_t)gy * (uint32_t)P.width + (uint32_t)x) * 0x9E3779B1u + (uint32_t)sample * 0x85EBCA77u;
     h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
     fx = fx + (float)(h & 0xFFFFu) / 65536.0f;
     fy = fy + (float)(h >> 16) / 65536.0f;
@@ -128,6 +134,7 @@ __device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) {
   const float sy = (uvy - 0.5f) * P.fov;
   return normalize3(madd3(madd3(ld3(P.fwd), sx, ld3(P.right)), sy, ld3(P.up)));
 }
+__device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) { return camera_dir(P, x, gy, P.sampleIndex); }
 
 // Drawing-order pass: one thread per tile looks at what the tile's centre pixel
 // sees first and files the tile under a cost class: 2 = a surface that bounces

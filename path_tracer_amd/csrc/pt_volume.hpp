@@ -383,8 +383,15 @@ __device__ __forceinline__ V3 march_volume(const FrameParams &P, const FramePara
 
 // main()'s last lines (raytrace.comp:703-704): the clamped colour goes to the rgba8 frame, and to the float frame
 // if there is one; with accumulation on, what goes there is the mean of the clamped samples so far.
+// PLANES (a launch that draws several samples): the clamped colour goes to this sample's plane, P.accum + the offset
+// outIdx carries, and nowhere else.
+template <bool PLANES = false>
 __device__ __forceinline__ void write_pixel(const FrameParams &P, const int accumCount, const int outIdx, const V3 fin) {
   float r = glclamp(fin.x, 0.0f, 1.0f), g = glclamp(fin.y, 0.0f, 1.0f), b = glclamp(fin.z, 0.0f, 1.0f);
+  if (PLANES) {
+    P.accum[outIdx] = make_float4(r, g, b, 0.0f);
+    return;
+  }
   if (P.accum) {
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (accumCount > 1) sum = P.accum[outIdx];
@@ -397,6 +404,31 @@ __device__ __forceinline__ void write_pixel(const FrameParams &P, const int accu
   }
   P.outRgba8[outIdx] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
   if (P.outF32) P.outF32[outIdx] = make_float4(r, g, b, 1.0f);
+}
+
+// The sample planes of one launch added to the running sum in sample order, one pixel per thread: the additions, the
+// division and the stores write_pixel performs when every sample has a launch of its own, on the same operands.
+__global__ void __launch_bounds__(256) pt_sum_samples_kernel(const float4 *planes, const int planeStride, const int nSamples, float4 *accum,
+                                                             const int countBefore, uint32_t *outRgba8, float4 *outF32) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= planeStride) return;
+  float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (countBefore > 0) sum = accum[i];
+  const float4 *p = planes + i;
+#pragma unroll 8
+  for (int s = 0; s < nSamples; ++s) {
+    const float4 c = p[(size_t)s * (size_t)planeStride];
+    sum = make_float4(sum.x + c.x, sum.y + c.y, sum.z + c.z, 0.0f);
+  }
+  accum[i] = sum;
+  float r = sum.x, g = sum.y, b = sum.z;
+  const int count = countBefore + nSamples;
+  if (count > 1) {
+    const float n = (float)count;
+    r = sum.x / n; g = sum.y / n; b = sum.z / n;
+  }
+  outRgba8[i] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
+  if (outF32) outF32[i] = make_float4(r, g, b, 1.0f);
 }
 
 // Frames without solids (no sphere, no ellipsoid, a volume): every pixel is its camera ray, the march of that ray

@@ -122,3 +122,4 @@ OPT_VOLUME_FILTER = 5
 OPT_FRAMES_IN_FLIGHT = 6
 OPT_HONOUR_MAX_DEPTH = 7
 OPT_PRESENT_LAG = 8
+OPT_SAMPLE_BATCH = 9

@@ -113,6 +113,46 @@ def test_trilinear_with_solids_within_tolerance(oracle):
     assert float((d8 <= 1).mean()) >= 0.999
 
 
+@pytest.mark.parametrize("kind", ["objects", "pooled", "objects_and_volume", "bands"])
+def test_samples_per_launch_do_not_change_the_frames(kind):
+    """pt_render_samples draws several samples per launch (PT_OPT_SAMPLE_BATCH): (tile, sample) tickets, one plane of
+    clamped colours per sample, the planes added up in sample order.  The frames must be the ones that one launch per
+    sample gives, bit for bit, whatever the batch: all samples in one launch, batches that do not divide the count,
+    a sum carried over calls (keep)."""
+    from path_tracer_amd import types as T
+
+    if kind == "objects":
+        sc = scenes.config2(328, 188, n_spheres=20, n_ellipsoids=6, max_depth=5)  # not multiples of the 8-pixel tile
+    elif kind == "pooled":
+        sc = scenes.config3(200, 120, n_spheres=300, max_depth=3)
+    elif kind == "objects_and_volume":
+        res = (70, 50, 61)
+        sc = scenes.config5(240, 136, voxels=(scenes.synthetic_walnut(res) // 8).astype(np.uint8), resolution=res)
+    else:
+        sc = scenes.config2(320, 180, n_spheres=12, n_ellipsoids=4, max_depth=4)
+    pc = sc.push_constants()
+    n = 7
+
+    def draw(batch, calls):
+        r = _renderer(sc, {T.OPT_SAMPLE_BATCH: batch})
+        if kind == "bands":
+            r.setRowBands(8, 1, 3)
+        first, keep = 0, False
+        for c in calls:
+            r.renderSamples(pc, first, c, keep=keep)
+            first, keep = first + c, True
+        r.present()
+        out = r.readbackRGBA8().copy(), r.readbackF32().copy()
+        r.shutdown()
+        return out
+
+    want8, wantf = draw(1, [n])
+    for batch, calls in ((0, [n]), (3, [n]), (2, [4, 3]), (0, [1, n - 1]), (64, [2, 2, 3])):
+        got8, gotf = draw(batch, calls)
+        np.testing.assert_array_equal(gotf.view(np.uint32), wantf.view(np.uint32), err_msg=f"{kind} batch {batch} calls {calls}")
+        np.testing.assert_array_equal(got8, want8, err_msg=f"{kind} batch {batch} calls {calls}")
+
+
 def test_sample_zero_is_the_plain_frame_and_mean_matches_oracle(oracle):
     sc = scenes.config2(320, 180, n_spheres=20, n_ellipsoids=6, max_depth=4)
     pc = sc.push_constants()
