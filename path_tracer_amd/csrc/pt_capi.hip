@@ -1285,6 +1285,7 @@ int pt_render_samples(PtRenderer *r, const PtPushConstants *pc, int first_sample
   if (r->sampleBatch != 1 && num_samples > 1 && !volumeOnly) {
     const size_t framePixels = (size_t)r->width * (size_t)std::max(r->localRows, 1);
     size_t freeBytes = 0, totalBytes = 0;
+    PT_HIP_CHECK(hipSetDevice(r->device));
     PT_HIP_CHECK(hipMemGetInfo(&freeBytes, &totalBytes));
     const size_t budget = std::min(kPlaneBudget, (freeBytes + r->dPlanes.cap) / 2); // never more than half of what is free
     size_t fit = budget / std::max<size_t>(framePixels * sizeof(float4), 1);

@@ -1,5 +1,6 @@
 """Long differential run, by hand: python tests/fuzz_random_scenes.py [first_seed] [count]
-Random scenes of tests/test_gpu_random_scenes.py (all three generators) against the oracle; prints the seeds that differ."""
+Random scenes of tests/test_gpu_random_scenes.py (all three generators) against the oracle, and three samples per pixel
+drawn in one launch against the same samples drawn launch by launch; prints the seeds that differ."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,16 @@ for seed in range(first, first + count):
     r.setScene(sc, honour_max_depth=True); pc = sc.push_constants()
     r.render(pc); r.present()
     g8, gf = r.readbackRGBA8(), r.readbackF32()
-    cnt = r.renderCounted(pc); r.shutdown()
+    cnt = r.renderCounted(pc)
+    # three samples per pixel: all in one launch against one launch per sample, bit for bit
+    frames = []
+    for batch in (0, 1):
+        r.setOption(T.OPT_SAMPLE_BATCH, batch)
+        r.renderSamples(pc, 0, 3); r.present()
+        frames.append((r.readbackRGBA8().copy(), r.readbackF32().copy()))
+    r.shutdown()
+    if not (np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1].view(np.uint32), frames[1][1].view(np.uint32))):
+        bad.append(seed); print("DIFF (samples per launch)", seed, flush=True)
     r8, rf, rc = orc.render(sc, nthreads=16)
     same_cnt = np.array_equal(cnt[:T.N_ALGORITHM_COUNTERS], rc[:T.N_ALGORITHM_COUNTERS])
     d8 = np.abs(g8.astype(np.int16) - r8.astype(np.int16)).max(axis=-1)
