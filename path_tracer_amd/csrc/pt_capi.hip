@@ -599,10 +599,17 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   PT_HIP_CHECK(hipMemsetAsync(scratch, 0, kScratchBytes, stream));
   if (P.tileOrder) {
     const size_t stage = ((size_t)pc->numSpheres + 4 * (size_t)pc->numEllipsoids) * sizeof(float4);
-    if (stage <= 48 * 1024)
-      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<true>, dim3((P.numTiles + 63) / 64), dim3(64), stage, stream, P);
-    else
-      hipLaunchKernelGGL(ptdev::pt_tile_order_kernel<false>, dim3((P.numTiles + 63) / 64), dim3(64), 0, stream, P);
+    const bool staged = stage <= 48 * 1024;
+    // a frame drawn alone: sixteen-wave workgroups, four lanes per tile; frames in flight: single waves (see the kernel)
+    if (mode == 0 && pipelined(r) && !fixed) {
+      const dim3 grid((P.numTiles + 63) / 64), block(64);
+      if (staged) hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<true, 1, 64>), grid, block, stage, stream, P);
+      else hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<false, 1, 64>), grid, block, 0, stream, P);
+    } else {
+      const dim3 grid((P.numTiles + 255) / 256), block(1024);
+      if (staged) hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<true, 4, 256>), grid, block, stage, stream, P);
+      else hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<false, 4, 256>), grid, block, 0, stream, P);
+    }
     PT_HIP_CHECK(hipGetLastError());
   }
   if (P.waveLog && (size_t)blocks * (size_t)(threads / 64) * 32 > r->dWaveLog.cap)
