@@ -224,9 +224,8 @@ int pt_render_static(PtRenderer *r, const PtPushConstants *pc, void *rgba8_dev, 
  * sample per pixel at the pixel corner and never calls its random(), reference
  * shaders/raytrace.comp:117-119, 692-700).  Draws sub-pixel samples
  * first_sample .. first_sample + num_samples - 1 and leaves the mean of the
- * clamped samples in the output frames.  Scenes with solids draw several
- * samples per launch (PT_OPT_SAMPLE_BATCH): the launch hands out (tile, sample)
- * pairs, so the chip idles at the end of the call instead of at the end of
+ * clamped samples in the output frames.  A call draws several samples per
+ * launch (PT_OPT_SAMPLE_BATCH): the launch hands out (tile, sample) pairs, so the chip idles at the end of the call instead of at the end of
  * every sample; each sample's clamped colours go to a plane of their own and
  * are added up in sample order, which gives the sum launches one by one give.  Sample 0 is the
  * reference's sample; sample s > 0 is offset inside the pixel by a

@@ -463,18 +463,36 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   if (mode == 0 && pc->numSpheres == 0 && pc->numEllipsoids == 0 && pc->numVolumes > 0 && !(r->tune & (1 << 25))) {
     P.volumeFilter = r->volumeFilter;
     P.sampleIndex = r->sampleIndex;
+    P.sampleCount = 1;
+    const size_t framePixels = (size_t)r->width * (size_t)std::max(r->localRows, 1);
+    const bool planes = r->accumulate && !fixed && r->batchSamples > 1;
     if (r->accumulate && !fixed) {
-      PT_HIP_CHECK(r->dAccum.reserve((size_t)r->width * (size_t)std::max(r->localRows, 1) * sizeof(float4)));
+      PT_HIP_CHECK(r->dAccum.reserve(framePixels * sizeof(float4)));
       P.accum = (float4 *)r->dAccum.p;
       P.accumCount = r->accumCount + 1;
     }
-    const int blocks = (P.numTiles + 3) / 4;
+    if (planes) { // as in the general kernel below: one plane per sample of the launch, summed afterwards
+      PT_HIP_CHECK(r->dPlanes.reserve(framePixels * sizeof(float4) * (size_t)r->batchSamples));
+      P.accum = (float4 *)r->dPlanes.p;
+      P.accumCount = 0;
+      P.sampleCount = r->batchSamples;
+      P.planeStride = (int)framePixels;
+    }
+    const int blocks = (int)(((long long)P.numTiles * P.sampleCount + 3) / 4);
     // the common volume (bricked copy, extents that are powers of two, box starting at v0 = 0) has variants compiled
     // for it alone, one per filter
     const bool commonVolume = P.brickX > 0 && P.exactExtent != 0 && P.v0[0] == 0.0f && P.v0[1] == 0.0f && P.v0[2] == 0.0f;
-    if (commonVolume && P.volumeFilter == 0) hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<1>, dim3(blocks), dim3(256), 0, stream, P);
-    else if (commonVolume && P.volumeFilter == 1) hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<2>, dim3(blocks), dim3(256), 0, stream, P);
-    else hipLaunchKernelGGL(ptdev::pt_volume_frame_kernel<0>, dim3(blocks), dim3(256), 0, stream, P);
+    const int kind = commonVolume ? (P.volumeFilter == 0 ? 1 : 2) : 0;
+#define PT_LAUNCH_V(KIND_, SAMPLES_) hipLaunchKernelGGL((ptdev::pt_volume_frame_kernel<KIND_, SAMPLES_>), dim3(blocks), dim3(256), 0, stream, P)
+    if (planes) { if (kind == 1) PT_LAUNCH_V(1, true); else if (kind == 2) PT_LAUNCH_V(2, true); else PT_LAUNCH_V(0, true); }
+    else { if (kind == 1) PT_LAUNCH_V(1, false); else if (kind == 2) PT_LAUNCH_V(2, false); else PT_LAUNCH_V(0, false); }
+#undef PT_LAUNCH_V
+    PT_HIP_CHECK(hipGetLastError());
+    if (planes) {
+      hipLaunchKernelGGL(ptdev::pt_sum_samples_kernel, dim3((unsigned int)((framePixels + 255) / 256)), dim3(256), 0, stream,
+                         (const float4 *)r->dPlanes.p, (int)framePixels, r->batchSamples, (float4 *)r->dAccum.p, r->accumCount,
+                         P.outRgba8, P.outF32);
+    }
     PT_HIP_CHECK(hipGetLastError());
     if (!fixed) { r->lastSlot = slot; r->slotDrawn[slot] = true; r->renderedSincePresent = true; }
     r->lastBlocks = blocks;
@@ -1286,10 +1304,9 @@ int pt_render_samples(PtRenderer *r, const PtPushConstants *pc, int first_sample
   // Samples per launch.  One launch per sample ends every sample on its slowest pixels with most of the chip idle;
   // a launch that draws several samples hands out (tile, sample) tickets and ends once.  Each sample of the launch
   // needs a float4 plane of the frame (4K: 133 MB), summed up in sample order afterwards, so the result is the one the
-  // launches one by one give.  Frames without solids keep one launch per sample (the volume kernel has no tickets).
+  // launches one by one give.  (Frames without solids: the volume kernel's waves take (tile, sample) pairs the same way.)
   int batch = 1;
-  const bool volumeOnly = pc->numSpheres == 0 && pc->numEllipsoids == 0 && pc->numVolumes > 0 && !(r->tune & (1 << 25));
-  if (r->sampleBatch != 1 && num_samples > 1 && !volumeOnly) {
+  if (r->sampleBatch != 1 && num_samples > 1) {
     const size_t framePixels = (size_t)r->width * (size_t)std::max(r->localRows, 1);
     size_t freeBytes = 0, totalBytes = 0;
     PT_HIP_CHECK(hipSetDevice(r->device));

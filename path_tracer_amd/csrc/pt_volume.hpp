@@ -437,16 +437,25 @@ __global__ void __launch_bounds__(256) pt_sum_samples_kernel(const float4 *plane
 // third of the general kernel's registers, so twice as many waves are resident to cover the latency of the voxel
 // loads, which is what bounds the march there.
 // KIND: see march_volume; the host launches the variant the volume and the filter qualify for.
-template <int KIND>
+// SAMPLES: the variant for launches that draw several samples of every pixel (P.sampleCount): a wave takes one
+// (tile, sample) pair, the samples of a tile next to each other, and the colour goes to the sample's plane.
+template <int KIND, bool SAMPLES = false>
 __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams P) {
   __shared__ float s_div255[256];
   s_div255[threadIdx.x] = (float)threadIdx.x / 255.0f; // the workgroup has 256 threads
   __syncthreads();
-  const int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  int sample = 0;
+  if (SAMPLES) {
+    if (tile >= P.numTiles * P.sampleCount) return;
+    const int q = tile / P.sampleCount;
+    sample = tile - q * P.sampleCount;
+    tile = q;
+  }
   if (tile >= P.numTiles) return;
   int x, ly, gy;
   if (!tile_pixel(P, tile, (int)(threadIdx.x & 63), x, ly, gy)) return;
-  const V3 curD = camera_dir(P, x, gy), rO = ld3(P.cam);
+  const V3 curD = camera_dir(P, x, gy, P.sampleIndex + sample), rO = ld3(P.cam);
   V3 fin = mk3(0, 0, 0);
   float thr = 1.0f;
   unsigned int steps;
@@ -465,7 +474,7 @@ __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams 
     const V3 bg = mk3(P.bgBottom[0] * omt + P.bgTop[0] * t, P.bgBottom[1] * omt + P.bgTop[1] * t, P.bgBottom[2] * omt + P.bgTop[2] * t);
     fin = add3(fin, scale3(bg, thr));
   }
-  write_pixel(P, P.accumCount, ly * P.width + x, fin);
+  write_pixel<SAMPLES>(P, P.accumCount, ly * P.width + x + (SAMPLES ? sample * P.planeStride : 0), fin);
 }
 
 } // namespace ptdev

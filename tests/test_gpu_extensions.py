@@ -113,7 +113,7 @@ def test_trilinear_with_solids_within_tolerance(oracle):
     assert float((d8 <= 1).mean()) >= 0.999
 
 
-@pytest.mark.parametrize("kind", ["objects", "pooled", "objects_and_volume", "bands"])
+@pytest.mark.parametrize("kind", ["objects", "pooled", "objects_and_volume", "bands", "volume", "volume_trilinear"])
 def test_samples_per_launch_do_not_change_the_frames(kind):
     """pt_render_samples draws several samples per launch (PT_OPT_SAMPLE_BATCH): (tile, sample) tickets, one plane of
     clamped colours per sample, the planes added up in sample order.  The frames must be the ones that one launch per
@@ -128,13 +128,15 @@ def test_samples_per_launch_do_not_change_the_frames(kind):
     elif kind == "objects_and_volume":
         res = (70, 50, 61)
         sc = scenes.config5(240, 136, voxels=(scenes.synthetic_walnut(res) // 8).astype(np.uint8), resolution=res)
+    elif kind in ("volume", "volume_trilinear"):  # frames without solids: the volume kernel, a wave per (tile, sample)
+        sc = _small_volume_scene(w=328, h=188)
     else:
         sc = scenes.config2(320, 180, n_spheres=12, n_ellipsoids=4, max_depth=4)
     pc = sc.push_constants()
     n = 7
 
     def draw(batch, calls):
-        r = _renderer(sc, {T.OPT_SAMPLE_BATCH: batch})
+        r = _renderer(sc, {T.OPT_SAMPLE_BATCH: batch, T.OPT_VOLUME_FILTER: 1 if kind == "volume_trilinear" else 0})
         if kind == "bands":
             r.setRowBands(8, 1, 3)
         first, keep = 0, False
