@@ -157,6 +157,8 @@ struct PtRenderer {
   // output
   DevBuf dRgba8[kMaxSlots], dF32[kMaxSlots], dScratch[kMaxSlots]; // per slot; dScratch: see kScratchBytes
   DevBuf dTileOrder[kMaxSlots];           // 3 x numTiles tile indices (one list per cost class)
+  int orderParity[kMaxSlots] = {};        // which of the slot's two sets of class counters the next ordered frame uses
+  bool orderClean[kMaxSlots] = {};        // that set was cleared by the drawing-order pass of the slot's previous frame
   int tileOrder = 2;             // PT_OPT_TILE_ORDER: 0 off, 1 on, 2 decided per frame
   float ellCenterMax = 0.0f, ellScale = 0.0f; // see FrameParams
   bool sphereFilter = false;     // the sphere pairs of the image carry the filter constant (FrameParams::sphereFilter)
@@ -199,7 +201,7 @@ struct PtComm {
 
 namespace {
 
-// dScratch: class counts (3 x 4 B) at +16, counters (PT_CNT_COUNT x 8 B) at +64, tile-ticket counters at +512
+// dScratch: class counts (two sets of 3 x 4 B, used alternately) at +16 and +32, counters (PT_CNT_COUNT x 8 B) at +64, tile-ticket counters at +512
 static_assert(64 + PT_CNT_COUNT * sizeof(uint64_t) <= 512, "the work counters must end before the ticket counters");
 constexpr size_t kPlaneBudget = (size_t)16 << 30; // pt_render_samples: device memory the sample planes of one launch may take
 constexpr size_t kScratchBytes = 512 + (size_t)ptdev::kTicketGroups * ptdev::kTicketStride * sizeof(unsigned int);
@@ -516,7 +518,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
       PT_HIP_CHECK(r->dTileOrder[slot].reserve((size_t)P.numTiles * 3 * sizeof(int)));
       P.tileOrder = (int *)r->dTileOrder[slot].p;
     }
-    P.classCount = (unsigned int *)(scratch + 16);
+    P.classCount = (unsigned int *)(scratch + 16 + 16 * (fixed ? 0 : r->orderParity[slot])); // two sets, see the memset below
   }
 
   // Launch geometry: persistent workgroups, 16 waves per CU.  Objects are
@@ -614,19 +616,27 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
   if ((r->tune >> 27) & 7) blocks = std::max(1, (r->computeUnits * blocksPerCu) >> (((r->tune >> 27) & 7) - 1));
   blocks = (int)std::min<long long>(blocks, std::max<long long>(blocksNeeded, 1));
 
-  PT_HIP_CHECK(hipMemsetAsync(scratch, 0, kScratchBytes, stream));
+  // The counter block is cleared in front of the frame -- by a memset, or, where the drawing-order pass runs anyway,
+  // by that pass: it clears the tickets and work counters of its own frame and the class counters of the next ordered
+  // frame of the slot (two sets of class counters alternate, at +16 and +32), which leaves one launch less per frame.
+  const bool selfClear = P.tileOrder != nullptr && !fixed;
+  if (!(selfClear && r->orderClean[slot])) PT_HIP_CHECK(hipMemsetAsync(scratch, 0, kScratchBytes, stream));
+  if (!fixed) r->orderClean[slot] = false; // until this frame's pass is queued
+  unsigned int *const clearWords = selfClear ? (unsigned int *)(scratch + 64) : nullptr;
+  const int clearCount = (int)((kScratchBytes - 64) / sizeof(unsigned int));
+  unsigned int *const clearNextClass = selfClear ? (unsigned int *)(scratch + 16 + 16 * (r->orderParity[slot] ^ 1)) : nullptr;
   if (P.tileOrder) {
     const size_t stage = ((size_t)pc->numSpheres + 4 * (size_t)pc->numEllipsoids) * sizeof(float4);
     const bool staged = stage <= 48 * 1024;
     // a frame drawn alone: sixteen-wave workgroups, four lanes per tile; frames in flight: single waves (see the kernel)
     if (mode == 0 && pipelined(r) && !fixed) {
       const dim3 grid((P.numTiles + 63) / 64), block(64);
-      if (staged) hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<true, 1, 64>), grid, block, stage, stream, P);
-      else hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<false, 1, 64>), grid, block, 0, stream, P);
+      if (staged) hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<true, 1, 64>), grid, block, stage, stream, P, clearWords, clearCount, clearNextClass);
+      else hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<false, 1, 64>), grid, block, 0, stream, P, clearWords, clearCount, clearNextClass);
     } else {
       const dim3 grid((P.numTiles + 255) / 256), block(1024);
-      if (staged) hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<true, 4, 256>), grid, block, stage, stream, P);
-      else hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<false, 4, 256>), grid, block, 0, stream, P);
+      if (staged) hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<true, 4, 256>), grid, block, stage, stream, P, clearWords, clearCount, clearNextClass);
+      else hipLaunchKernelGGL((ptdev::pt_tile_order_kernel<false, 4, 256>), grid, block, 0, stream, P, clearWords, clearCount, clearNextClass);
     }
     PT_HIP_CHECK(hipGetLastError());
   }
@@ -662,6 +672,7 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
     PT_HIP_CHECK(hipGetLastError());
   }
   if (!fixed) { r->lastSlot = slot; r->slotDrawn[slot] = true; r->renderedSincePresent = true; }
+  if (selfClear) { r->orderParity[slot] ^= 1; r->orderClean[slot] = true; }
   r->lastBlocks = blocks;
   r->lastThreads = threads;
   r->lastLds = (int)ldsBytes;

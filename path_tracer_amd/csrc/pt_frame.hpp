@@ -150,8 +150,16 @@ __device__ __forceinline__ V3 camera_dir(const FrameParams &P, int x, int gy) { 
 // at 1080p with 64 objects) and <1, 64>, single waves, with frames in flight: there the pass of the next frame has
 // to find room beside the previous frame's resident waves, which leave one by one, and a workgroup of sixteen
 // waves waits for a whole compute unit (measured: the frame rate with two in flight drops by 3 %).
+// clearWords / clearCount: the frame's ticket and work counters, cleared here so that no clearing launch has to
+// precede the pass; clearNextClass: the three class counters the NEXT ordered frame of these buffers will use (a
+// frame's own were cleared by the pass before it; the two sets alternate).  Null: the host cleared everything.
 template <bool STAGED, int LANES, int TILES>
-__global__ void __launch_bounds__(LANES * TILES) pt_tile_order_kernel(const FrameParams P) {
+__global__ void __launch_bounds__(LANES * TILES) pt_tile_order_kernel(const FrameParams P, unsigned int *clearWords, int clearCount,
+                                                                      unsigned int *clearNextClass) {
+  if (blockIdx.x == 0 && clearWords) {
+    for (int i = threadIdx.x; i < clearCount; i += blockDim.x) clearWords[i] = 0u;
+    if (threadIdx.x < 3) clearNextClass[threadIdx.x] = 0u;
+  }
   // STAGED: the spheres and ellipsoid records are copied to LDS first (the loops below
   // would otherwise wait for one dependent global load per object)
   extern __shared__ float4 s_objs[];
