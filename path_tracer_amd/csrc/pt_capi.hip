@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -485,7 +486,35 @@ int launch_frame(PtRenderer *r, const PtPushConstants *pc, int mode, const Frame
     // for it alone, one per filter
     const bool commonVolume = P.brickX > 0 && P.exactExtent != 0 && P.v0[0] == 0.0f && P.v0[1] == 0.0f && P.v0[2] == 0.0f;
     const int kind = commonVolume ? (P.volumeFilter == 0 ? 1 : 2) : 0;
-#define PT_LAUNCH_V(KIND_, SAMPLES_) hipLaunchKernelGGL((ptdev::pt_volume_frame_kernel<KIND_, SAMPLES_>), dim3(blocks), dim3(256), 0, stream, P)
+    // Pixels that can see the box: the bounding rectangle of its eight corners on the image plane, two pixels of margin
+    // (the shader's slab test differs from the exact one by rounding errors, a millionth of that).  Only when every
+    // corner lies well in front of the eye and everything is finite; otherwise the whole frame.
+    int rect[4] = {INT_MIN / 2, INT_MIN / 2, INT_MAX / 2, INT_MAX / 2};
+    {
+      const double fwd[3] = {P.fwd[0], P.fwd[1], P.fwd[2]}, rgt[3] = {P.right[0], P.right[1], P.right[2]}, upv[3] = {P.up[0], P.up[1], P.up[2]};
+      double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+      bool ok = true;
+      for (int c = 0; c < 8 && ok; ++c) {
+        double v[3], len2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+          v[a] = (double)(((c >> a) & 1) ? P.boxMax[a] : P.boxMin[a]) - (double)P.cam[a];
+          len2 += v[a] * v[a];
+        }
+        const double za = v[0] * fwd[0] + v[1] * fwd[1] + v[2] * fwd[2];
+        const double xb = v[0] * rgt[0] + v[1] * rgt[1] + v[2] * rgt[2], yc = v[0] * upv[0] + v[1] * upv[1] + v[2] * upv[2];
+        if (!(za > 1e-3 * std::sqrt(len2)) || !std::isfinite(len2)) { ok = false; break; }
+        const double fx = (xb / za / ((double)P.aspect * (double)P.fov) + 0.5) * (double)P.width;
+        const double fy = (1.0 - (yc / za / (double)P.fov + 0.5)) * (double)P.height;
+        if (!std::isfinite(fx) || !std::isfinite(fy) || std::fabs(fx) > 1e8 || std::fabs(fy) > 1e8) { ok = false; break; }
+        lo[0] = std::min(lo[0], fx); hi[0] = std::max(hi[0], fx);
+        lo[1] = std::min(lo[1], fy); hi[1] = std::max(hi[1], fy);
+      }
+      if (ok) {
+        rect[0] = (int)std::floor(lo[0]) - 2; rect[1] = (int)std::floor(lo[1]) - 2;
+        rect[2] = (int)std::ceil(hi[0]) + 2;  rect[3] = (int)std::ceil(hi[1]) + 2;
+      }
+    }
+#define PT_LAUNCH_V(KIND_, SAMPLES_) hipLaunchKernelGGL((ptdev::pt_volume_frame_kernel<KIND_, SAMPLES_>), dim3(blocks), dim3(256), 0, stream, P, rect[0], rect[1], rect[2], rect[3])
     if (planes) { if (kind == 1) PT_LAUNCH_V(1, true); else if (kind == 2) PT_LAUNCH_V(2, true); else PT_LAUNCH_V(0, true); }
     else { if (kind == 1) PT_LAUNCH_V(1, false); else if (kind == 2) PT_LAUNCH_V(2, false); else PT_LAUNCH_V(0, false); }
 #undef PT_LAUNCH_V

@@ -439,8 +439,11 @@ __global__ void __launch_bounds__(256) pt_sum_samples_kernel(const float4 *plane
 // KIND: see march_volume; the host launches the variant the volume and the filter qualify for.
 // SAMPLES: the variant for launches that draw several samples of every pixel (P.sampleCount): a wave takes one
 // (tile, sample) pair, the samples of a tile next to each other, and the colour goes to the sample's plane.
+// (rx0, ry0) - (rx1, ry1): pixels outside this rectangle cannot see the box (the host projects the box's corners and
+// adds a margin of two pixels; the whole frame where it cannot tell).  A tile without a pixel inside skips the march and
+// its slab test: the march's answer for such a ray is (-1, -1, -1) with no sample taken.
 template <int KIND, bool SAMPLES = false>
-__global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams P) {
+__global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams P, const int rx0, const int ry0, const int rx1, const int ry1) {
   __shared__ float s_div255[256];
   s_div255[threadIdx.x] = (float)threadIdx.x / 255.0f; // the workgroup has 256 threads
   __syncthreads();
@@ -458,9 +461,12 @@ __global__ void __launch_bounds__(256) pt_volume_frame_kernel(const FrameParams 
   const V3 curD = camera_dir(P, x, gy, P.sampleIndex + sample), rO = ld3(P.cam);
   V3 fin = mk3(0, 0, 0);
   float thr = 1.0f;
-  unsigned int steps;
-  const V3 vol = march_volume<true, KIND>(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
-                              kMaxDistance, steps);
+  unsigned int steps = 0u;
+  V3 vol = mk3(-1.0f, -1.0f, -1.0f);
+  const bool maySee = x + 1 >= rx0 && x <= rx1 && gy + 1 >= ry0 && gy <= ry1; // a sample lies in [x, x + 1) x [gy, gy + 1)
+  if (__builtin_amdgcn_ballot_w64(maySee) != 0ull)
+    vol = march_volume<true, KIND>(P, P, s_div255, [&]() -> float4 { return P.image[P.offMat + 5 * P.volMaterial + 4]; }, rO, curD,
+                                   kMaxDistance, steps);
   float volumeAlpha = 0.0f;
   if (vol.x >= 0.0f) volumeAlpha = glclamp(length3(vol) / length3(mk3(1.0f, 1.0f, 1.0f)), 0.0f, 1.0f); // :618-620
   if (volumeAlpha > 0.0f) {                                                                              // :624-627

@@ -1,4 +1,5 @@
-"""Long differential run, by hand: python tests/fuzz_random_scenes.py [first_seed] [count]
+"""Long differential run, by hand: python tests/fuzz_random_scenes.py [first_seed] [count] [volume]
+(with a third argument every scene is a frame without solids)
 Random scenes of tests/test_gpu_random_scenes.py (all three generators) against the oracle, and three samples per pixel
 drawn in one launch against the same samples drawn launch by launch; prints the seeds that differ."""
 import os, sys
@@ -11,11 +12,13 @@ import test_gpu_random_scenes as G
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+only_volume = len(sys.argv) > 3
 oracle_py.lib()
 orc = oracle_py
 bad = []
 for seed in range(first, first + count):
-    sc = G.random_hall_of_mirrors(seed) if seed % 10 == 0 else G.random_volume_frame(seed) if seed % 10 == 5 else G.random_scene(seed)
+    sc = (G.random_volume_frame(seed) if only_volume or seed % 10 == 5 else
+          G.random_hall_of_mirrors(seed) if seed % 10 == 0 else G.random_scene(seed))
     r = HipRenderer(); assert r.initialize(sc.width, sc.height)
     r.setScene(sc, honour_max_depth=True); pc = sc.push_constants()
     r.render(pc); r.present()
